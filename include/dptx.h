@@ -1,0 +1,154 @@
+/* dptx.h -- C ABI of libdptx.so: the MI355X (gfx950) DPT-Hybrid-384 inference engine.
+ *
+ * This is the drop-in boundary for ONE path of EPFL-VILAB/omnidata: the forward pass of
+ *   DPTDepthModel(backbone='vitb_rn50_384', num_channels={3|1})
+ * (omnidata_tools/torch/modules/midas/dpt_depth.py:87-107, DPT.forward :67-85) that the
+ * reference reaches from demo.py:140 (`model(img_tensor)`) and from the torch.hub entry
+ * points `surface_normal_dpt_hybrid_384` / `depth_dpt_hybrid_384` (README.md:23-29).
+ * The reference has no FFI of its own (it is pure Python on ATen); every entry point
+ * below names the reference interface it replaces.  Plain pointers and sizes only; no
+ * torch types, no C++ exceptions across the boundary.  All functions return 0 on success
+ * or a negative DPTX_E_* code; dptx_last_error() gives the message.
+ *
+ * Ownership: the caller owns x / y device buffers (e.g. torch tensors' data_ptr());
+ * the engine owns its packed weights and activation arena and never frees caller memory.
+ * Threading: one handle per (device, stream); a handle is not re-entrant (the reference
+ * is not either: vit.py:158 keeps hook outputs in a module-global dict); independent
+ * handles may be used from independent threads.
+ */
+#ifndef DPTX_H_
+#define DPTX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dptx_engine* dptx_handle;
+
+enum {
+  DPTX_OK = 0,
+  DPTX_E_INVALID = -1,   /* bad argument / wrong call order            */
+  DPTX_E_KEY = -2,       /* unknown / missing / mis-shaped tensor key  */
+  DPTX_E_HIP = -3,       /* a HIP runtime call failed                  */
+  DPTX_E_NODEVICE = -4,  /* compute entry point called on a host-only handle */
+  DPTX_E_ALLOC = -5
+};
+
+/* arithmetic type of the MFMA operands and of the stored activations */
+enum { DPTX_DTYPE_BF16 = 0, DPTX_DTYPE_FP16 = 1 };
+/* dtype of caller-side image / result buffers */
+enum { DPTX_IO_FP32 = 0 };
+
+typedef struct dptx_config {
+  int32_t num_channels;  /* 3 = surface normals, 1 = depth (dpt_depth.py:88 num_channels)      */
+  int32_t max_batch;     /* arena is sized for this many 384x384 images per dptx_forward call   */
+  int32_t dtype;         /* DPTX_DTYPE_*                                                        */
+  int32_t device_id;     /* HIP device ordinal; -1 = host-only handle (weight packing only)     */
+  int32_t non_negative;  /* final ReLU of the head (dpt_depth.py:88,98 non_negative=True)       */
+  int32_t ws_form;       /* 0: (w-mean)/(std+eps) timm 0.4.x;  1: (w-mean)/sqrt(var+eps)        */
+  float   ws_eps;        /* StdConv2dSame eps (timm vit_base_r50_s16: 1e-8)                     */
+  int32_t reserved[8];   /* must be zero                                                        */
+} dptx_config;
+
+/* Fills *cfg with the reference defaults: C=3, max_batch=32, bf16, device 0, non_negative=1,
+ * ws_form=0, ws_eps=1e-8. */
+void dptx_default_config(dptx_config* cfg);
+
+/* Replaces the constructor DPTDepthModel(...) (dpt_depth.py:87-104). */
+int dptx_create(dptx_handle* out, const dptx_config* cfg);
+void dptx_destroy(dptx_handle h);
+
+/* Replaces `model.load_state_dict(state_dict)` (demo.py:72; BaseModel.load base_model.py:4-16),
+ * one tensor at a time.  `ref_key` is the reference state_dict key after the Lightning
+ * `model.` prefix has been stripped (demo.py:65-70), e.g.
+ * "pretrained.model.blocks.0.attn.qkv.weight"; `host_fp32` is a contiguous fp32 host array of
+ * the given shape (OIHW for convs, [out,in] for linears).  Keys the forward never reads
+ * (pretrained.model.norm.*, pretrained.model.head.*, scratch.refinenet4.resConfUnit1.*) are
+ * accepted and ignored.  Unknown keys or wrong shapes -> DPTX_E_KEY. */
+int dptx_load_tensor(dptx_handle h, const char* ref_key, const float* host_fp32,
+                     const int64_t* shape, int32_t ndim);
+
+/* Strict check + packing: every tensor the forward reads must have been loaded (else DPTX_E_KEY,
+ * the message lists the missing keys -- mirrors load_state_dict(strict=True)).  Folds the
+ * StdConv2dSame weight standardisation (input independent) into the conv weights, re-lays
+ * OIHW -> [O][kh][kw][I], converts GEMM operands to cfg.dtype and builds one contiguous blob.
+ * On a device handle the blob is uploaded and the activation arena is allocated. */
+int dptx_finalize_weights(dptx_handle h);
+
+/* Size of the packed blob (valid after finalize, or for any handle: depends only on cfg). */
+size_t dptx_packed_bytes(dptx_handle h);
+/* Copies the packed blob to host memory (works on host-only handles: used by CPU tests). */
+int dptx_export_packed_host(dptx_handle h, void* dst_host, size_t bytes);
+/* Copies the packed blob to / from a caller DEVICE buffer on `stream`.  This is the multi-GPU
+ * start-up path: rank 0 finalizes, exports into a torch uint8 tensor, torch.distributed
+ * (RCCL) broadcasts it over xGMI, the other ranks import it instead of packing themselves. */
+int dptx_export_packed_device(dptx_handle h, void* dst_dev, size_t bytes, void* stream);
+int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, void* stream);
+
+/* Bytes of device memory held by the handle (packed weights + activation arena). */
+size_t dptx_workspace_bytes(dptx_handle h);
+
+/* Replaces `DPTDepthModel.forward(x)` (dpt_depth.py:106-107 -> DPT.forward :67-85).
+ *   x_dev : [batch,3,384,384] contiguous NCHW, x_dtype = DPTX_IO_FP32; normal model expects
+ *           values in [0,1], depth model in [-1,1] (omnidata_tools/torch/README.md:46,49).
+ *   y_dev : [batch,C,384,384] contiguous NCHW fp32 (for C=1 this is bit-identical to the
+ *           reference's squeezed [batch,384,384]); >= 0 when non_negative, NOT clamped to 1
+ *           (callers clamp: demo.py:140).
+ * Asynchronous on `stream` (a hipStream_t; NULL = default stream). 1 <= batch <= max_batch. */
+int dptx_forward(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev,
+                 int32_t batch, void* stream);
+
+/* Debug hook for stage-level parity (SURVEY.md A.1 tap names: "stem","s0","s1","s2","tok0",
+ * "blk0".."blk11","l3","l4","l1_rn".."l4_rn","p4","p3","p2","p1","h0","h1").  Copies the
+ * stage activation of the LAST forward, converted to fp32 in the engine's internal layout
+ * (NHWC for feature maps, [batch*577,768] for tokens), to dst_host.  *shape4 receives
+ * {batch, H, W, C} (or {batch,577,768,1}).  Returns DPTX_E_KEY for unknown names. */
+int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_floats,
+             int64_t shape4[4]);
+/* The fp32 token stream is updated in place by the 12 blocks; "tok0"/"blkN" taps therefore need
+ * copies.  on=1 allocates 13 snapshots and makes dptx_forward record them (debug only). */
+int dptx_enable_taps(dptx_handle h, int on);
+
+/* Number of kernel launches issued by one dptx_forward and algorithmic vs executed MACs
+ * per image (algorithmic 127.624e9 for C=3; executed differs because out_conv
+ * is commuted in front of the x2 upsample). */
+int dptx_forward_info(dptx_handle h, int64_t* launches, double* algorithmic_macs,
+                      double* executed_macs);
+
+const char* dptx_last_error(dptx_handle h);
+const char* dptx_version(void);
+
+/* ---- op-level entry points (unit tests + micro-benchmarks of the individual kernels) ----
+ * dtype: DPTX_DTYPE_*.  All pointers are device pointers; row-major / NHWC. */
+
+/* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+R); A,W,C,R 16-bit `dtype`; bias fp32 or NULL;
+ * act: 0 none, 1 relu, 2 gelu(erf); c_fp32/r_fp32 select fp32 C / R. */
+int dptx_op_gemm(int32_t dtype, const void* A, const void* W, const float* bias, const void* R,
+                 void* C, int32_t M, int32_t N, int32_t K, int32_t act, int32_t a_fp32,
+                 int32_t c_fp32, int32_t r_fp32, void* stream);
+/* NHWC conv as implicit GEMM: X[B,H,W,Cin], Wt[Cout][k][k][Cin], Y[B,Ho,Wo,Cout]. */
+int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias, const void* R,
+                 void* Y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                 int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
+                 int32_t Wo, int32_t a_relu, int32_t act, void* stream);
+/* qkv[B*S,3*H*64] packed (which, head, dim) -> out[B*S,H*64]; softmax(q k^T / 8) v. */
+int dptx_op_attention(int32_t dtype, const void* qkv, void* out, int32_t B, int32_t S,
+                      int32_t heads, void* stream);
+/* y16[M,768] = LayerNorm(x32[M,768]; gamma, beta, eps) */
+int dptx_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta,
+                      void* y, int32_t M, int32_t C, float eps, void* stream);
+/* GroupNorm(32) (+ optional residual R, + optional ReLU) on NHWC 16-bit, out of place. */
+int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const float* beta,
+                      const void* R, void* Y, int32_t B, int32_t HW, int32_t C, int32_t relu,
+                      float eps, void* scratch_f32, void* stream);
+/* bilinear x2, align_corners=True, NHWC 16-bit. */
+int dptx_op_upsample2x(int32_t dtype, const void* X, void* Y, int32_t B, int32_t H, int32_t W,
+                       int32_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPTX_H_ */

@@ -1,0 +1,186 @@
+// attention.hip -- fused softmax(Q K^T / sqrt(64)) V for the 12 ViT blocks (timm Attention,
+// call site vit.py:150-151; N = 577 tokens, 12 heads x 64).  Scores never reach HBM.
+//
+// Input  qkv[B*S][3*H*64] 16-bit, feature index = which*H*64 + head*64 + dim (timm's
+//        reshape(B,N,3,heads,64) packing); output out[B*S][H*64] 16-bit.
+// Grid   (ceil(S/128), H, B); 4 waves, each owns 32 query rows.
+// Per 64-key tile (shared by the 4 waves through LDS):
+//   K  tile [64 keys][64 d]   row-major, 16-B chunks XOR-swizzled (same scheme as gemm.hip)
+//   V^T tile [64 d][64 keys]  transposed while staging (two adjacent keys per ds_write_b32),
+//                             same XOR swizzle keyed on the d row, key order permuted (bits 2<->3
+//                             within each 32-key half) so that the P^T accumulator registers of
+//                             the first MFMA are directly the B operand of the second one -- no
+//                             cross-lane movement of P.
+//   S^T[key][q] = mfma32x32x16(K, Q)   (swapped operands: a lane owns ONE query column, so the
+//                                       row max / row sum are in-lane + one lane^32 exchange)
+//   online softmax in fp32 (exp2 with the 1/8 scale folded into the exponent constant)
+//   O^T[d][q] += mfma32x32x16(V^T, P^T)
+#include "common.h"
+#include "kernels.h"
+
+namespace dptx {
+
+constexpr int ATT_D = 64;
+constexpr int ATT_KT = 64;                 // keys per tile
+constexpr int ATT_K_BYTES = ATT_KT * 128;  // 8 KB
+constexpr int ATT_V_BYTES = ATT_D * 128;   // 8 KB
+constexpr int ATT_STAGE = ATT_K_BYTES + ATT_V_BYTES;
+
+__device__ __forceinline__ int vt_pos(int key) {  // swap bits 2 and 3
+  return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                           int S, int H) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int ld = 3 * H * ATT_D;
+  const long long row0 = (long long)b * S;
+  const uint16_t* qbase = qkv + head * ATT_D;
+  const uint16_t* kbase = qkv + H * ATT_D + head * ATT_D;
+  const uint16_t* vbase = qkv + 2 * H * ATT_D + head * ATT_D;
+
+  // Q fragments (B operand: lane = query column, 8 consecutive d per k-step)
+  const int q = blockIdx.x * 128 + wave * 32 + lr;
+  const int qc = q < S ? q : S - 1;
+  uint4 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(qbase + (row0 + qc) * ld + ks * 16 + lh * 8);
+
+  // staging: thread t loads 16 B (d chunk t&7) of K for keys (t>>3), (t>>3)+32 and of V for the
+  // adjacent key pair 2*(t>>3), 2*(t>>3)+1 (adjacent keys stay adjacent under vt_pos)
+  const int kc = tid & 7, kr = tid >> 3;
+  uint4 rk[2], rv[2];
+  auto load_kv = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = t * ATT_KT + kr + 32 * i;
+      const int vkey = t * ATT_KT + 2 * kr + i;
+      uint4 k4 = make_uint4(0, 0, 0, 0), v4 = k4;
+      if (key < S) k4 = *(const uint4*)(kbase + (row0 + key) * ld + kc * 8);
+      if (vkey < S) v4 = *(const uint4*)(vbase + (row0 + vkey) * ld + kc * 8);
+      rk[i] = k4;
+      rv[i] = v4;
+    }
+  };
+  auto store_kv = [&](int buf) {
+    char* sk = smem + buf * ATT_STAGE;
+    char* sv = sk + ATT_K_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = kr + 32 * i;
+      *(uint4*)(sk + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rk[i];
+    }
+    const int key_l = 2 * kr;  // even key of the pair, 0..62
+    const int pos = (key_l & 32) | vt_pos(key_l & 31);
+    const uint32_t w0[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
+    const uint32_t w1[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t a = (e & 1) ? (w0[e >> 1] >> 16) : (w0[e >> 1] & 0xffffu);
+      const uint32_t c = (e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu);
+      const int d = kc * 8 + e;
+      *(uint32_t*)(sv + d * 128 + ((((pos >> 3) ^ ((d >> 1) & 7))) << 4) + (pos & 7) * 2) = a | (c << 16);
+    }
+  };
+
+  f32x16_t o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  const float cexp = 0.125f * 1.4426950408889634f;  // softmax scale folded into exp2
+
+  const int ntiles = (S + ATT_KT - 1) / ATT_KT;
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = (t + 1) < ntiles;
+    if (more) load_kv(t + 1);
+    const char* sk = smem + (t & 1) * ATT_STAGE;
+    const char* sv = sk + ATT_K_BYTES;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16_t s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = sub * 32 + lr;
+        const int chunk = 2 * ks + lh;
+        const uint4 kf = *(const uint4*)(sk + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        s = T16<DT>::mfma32(kf, qf[ks], s);
+      }
+      // s[r] = <K[key], Q[q]> with key = t*64 + sub*32 + (r&3) + 8*(r>>2) + 4*lh, q = this lane's column
+      const int key0 = t * ATT_KT + sub * 32 + 4 * lh;
+      if (key0 + 28 + 3 >= S) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + (r & 3) + 8 * (r >> 2) >= S) s[r] = -1e30f;
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f((m_run - m_new) * cexp);
+      m_run = m_new;
+      float pv[16];
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = exp2f((s[r] - m_new) * cexp);
+        ps += pv[r];
+      }
+      l_run = l_run * alpha + ps;  // per-half partial sum; halves are added at the end
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      uint4 pf[2];
+      pf[0] = pack8<DT>(pv);
+      pf[1] = pack8<DT>(pv + 8);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int drow = dt * 32 + lr;
+          const int vchunk = sub * 4 + s2 * 2 + lh;
+          const uint4 vf = *(const uint4*)(sv + drow * 128 + ((vchunk ^ ((drow >> 1) & 7)) << 4));
+          o[dt] = T16<DT>::mfma32(vf, pf[s2], o[dt]);
+        }
+      }
+    }
+    if (more) store_kv((t + 1) & 1);
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q < S) {
+    uint16_t* op = out + (row0 + q) * (long long)(H * ATT_D) + head * ATT_D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = T16<DT>::pack2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
+        w.y = T16<DT>::pack2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(op + dt * 32 + 8 * g + 4 * lh) = w;
+      }
+  }
+}
+
+hipError_t launch_attention(int dtype, const void* qkv, void* out, int B, int S, int heads, hipStream_t stream) {
+  dim3 grid((S + 127) / 128, heads, B);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(attention_kernel<DT_BF16>, grid, dim3(256), 0, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(attention_kernel<DT_FP16>, grid, dim3(256), 0, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace dptx

@@ -1,0 +1,101 @@
+// common.h -- shared device helpers for the dptx kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dptx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int DT_BF16 = 0;
+constexpr int DT_FP16 = 1;
+
+// 16-bit storage/MFMA-operand type traits.  DT = 0: bf16, 1: fp16.
+template <int DT> struct T16;
+
+template <> struct T16<DT_BF16> {
+  static __device__ __forceinline__ float tof(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+  static __device__ __forceinline__ uint16_t fromf(float f) {
+    __bf16 h = (__bf16)f;  // RNE (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+  static __device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+template <> struct T16<DT_FP16> {
+  static __device__ __forceinline__ float tof(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  static __device__ __forceinline__ uint16_t fromf(float f) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    f16x2_t v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+  static __device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+// unpack 8 x 16-bit (one uint4) to 8 floats
+template <int DT>
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = T16<DT>::tof((uint16_t)(w[i] & 0xffffu));
+    f[2 * i + 1] = T16<DT>::tof((uint16_t)(w[i] >> 16));
+  }
+}
+template <int DT>
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = T16<DT>::pack2(f[0], f[1]);
+  v.y = T16<DT>::pack2(f[2], f[3]);
+  v.z = T16<DT>::pack2(f[4], f[5]);
+  v.w = T16<DT>::pack2(f[6], f[7]);
+  return v;
+}
+
+// ReLU on two packed 16-bit floats (bf16 or fp16: sign bit is bit 15 of each half).
+__device__ __forceinline__ uint32_t relu2(uint32_t v) {
+  uint32_t m = ((v >> 15) & 0x00010001u) * 0xffffu;
+  return v & ~m;
+}
+__device__ __forceinline__ uint4 relu8(uint4 v) {
+  v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Bijective XCD-aware remap of a 1-D block id: blocks that the dispatcher places on one
+// XCD (id % 8) receive a contiguous range of logical work-group ids, so neighbouring tiles
+// share that XCD's L2 (cdna_hip_programming.md T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int xcd = id & 7, idx = id >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace dptx

@@ -1,0 +1,821 @@
+// engine.hip -- libdptx.so host side: the C ABI of include/dptx.h, weight folding/packing, the
+// activation arena and the fixed kernel schedule of one DPT-Hybrid-384 forward.
+//
+// Reference being replaced (paths under omnidata_tools/torch/modules/midas/):
+//   dpt_depth.py:67-85  DPT.forward          -> Engine::forward
+//   vit.py:119-155      forward_flex         -> stem / stages / tokens / 12 blocks
+//   vit.py:61-99        forward_vit          -> readout + reassemble (act_postprocess3/4)
+//   blocks.py:263-341   RCU / FeatureFusion  -> fusion()
+//   dpt_depth.py:91-99  head                 -> head convs + head_out
+// timm 0.4.12 vit_base_resnet50_384 (vit.py:483) is restated per SURVEY.md A.2.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dptx.h"
+#include "kernels.h"
+
+using namespace dptx;
+
+namespace {
+
+constexpr int IMG = 384;
+constexpr int S_TOK = 577;
+constexpr int D_VIT = 768;
+constexpr int D_MLP = 3072;
+constexpr int N_HEADS = 12;
+constexpr int FEAT = 256;
+const int STAGE_DEPTH[3] = {3, 4, 9};
+const int STAGE_OUT[3] = {256, 512, 1024};
+const int STAGE_STRIDE[3] = {1, 2, 2};
+
+// ---------------------------------------------------------------- host 16-bit conversions
+inline uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                            // RNE
+  return (uint16_t)(u >> 16);
+}
+inline uint16_t f32_to_fp16(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (x >= 0x477ff000u) {  // >= 65520 rounds to inf
+    return (uint16_t)(sign | 0x7c00u);
+  }
+  if (x < 0x38800000u) {  // subnormal half (|f| < 2^-14)
+    if (x < 0x33000000u) return (uint16_t)sign;  // < 2^-25 -> 0
+    const int e = (int)(x >> 23);                // biased exponent
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;    // 24-bit significand
+    const int shift = 126 - e;                   // 14..24: result = m >> shift with RNE (units of 2^-24)
+    const uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u);
+    const uint32_t half = 1u << (shift - 1);
+    uint32_t r = q;
+    if (rem > half || (rem == half && (q & 1u))) r++;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = x - 0x38000000u;  // rebias exponent (127-15)<<23
+  const uint32_t rem = r & 0x1fffu;
+  r >>= 13;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+  return (uint16_t)(sign | r);
+}
+
+// --------------------------------------------------------------------------- weight spec
+enum Role { R_STDCONV, R_CONV, R_LINEAR, R_VEC, R_HEAD4, R_UNUSED };
+struct Spec {
+  std::string key;
+  std::vector<int64_t> shape;
+  Role role;
+};
+
+void add(std::vector<Spec>& v, const std::string& k, std::vector<int64_t> s, Role r) { v.push_back({k, std::move(s), r}); }
+
+// Mirrors omnidata_amd/weights.py:state_dict_spec (reference key names).
+std::vector<Spec> build_spec(int C) {
+  std::vector<Spec> v;
+  const std::string vp = "pretrained.model.";
+  add(v, vp + "cls_token", {1, 1, D_VIT}, R_VEC);
+  add(v, vp + "pos_embed", {1, S_TOK, D_VIT}, R_VEC);
+  const std::string bp = vp + "patch_embed.backbone.";
+  add(v, bp + "stem.conv.weight", {64, 3, 7, 7}, R_STDCONV);
+  add(v, bp + "stem.norm.weight", {64}, R_VEC);
+  add(v, bp + "stem.norm.bias", {64}, R_VEC);
+  int cin = 64;
+  for (int s = 0; s < 3; ++s) {
+    const int cout = STAGE_OUT[s], mid = cout / 4;
+    for (int b = 0; b < STAGE_DEPTH[s]; ++b) {
+      const std::string p = bp + "stages." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+      if (b == 0) {
+        add(v, p + "downsample.conv.weight", {cout, cin, 1, 1}, R_STDCONV);
+        add(v, p + "downsample.norm.weight", {cout}, R_VEC);
+        add(v, p + "downsample.norm.bias", {cout}, R_VEC);
+      }
+      add(v, p + "conv1.weight", {mid, cin, 1, 1}, R_STDCONV);
+      add(v, p + "norm1.weight", {mid}, R_VEC);
+      add(v, p + "norm1.bias", {mid}, R_VEC);
+      add(v, p + "conv2.weight", {mid, mid, 3, 3}, R_STDCONV);
+      add(v, p + "norm2.weight", {mid}, R_VEC);
+      add(v, p + "norm2.bias", {mid}, R_VEC);
+      add(v, p + "conv3.weight", {cout, mid, 1, 1}, R_STDCONV);
+      add(v, p + "norm3.weight", {cout}, R_VEC);
+      add(v, p + "norm3.bias", {cout}, R_VEC);
+      cin = cout;
+    }
+  }
+  add(v, vp + "patch_embed.proj.weight", {D_VIT, 1024, 1, 1}, R_CONV);
+  add(v, vp + "patch_embed.proj.bias", {D_VIT}, R_VEC);
+  for (int l = 0; l < 12; ++l) {
+    const std::string p = vp + "blocks." + std::to_string(l) + ".";
+    add(v, p + "norm1.weight", {D_VIT}, R_VEC);
+    add(v, p + "norm1.bias", {D_VIT}, R_VEC);
+    add(v, p + "attn.qkv.weight", {3 * D_VIT, D_VIT}, R_LINEAR);
+    add(v, p + "attn.qkv.bias", {3 * D_VIT}, R_VEC);
+    add(v, p + "attn.proj.weight", {D_VIT, D_VIT}, R_LINEAR);
+    add(v, p + "attn.proj.bias", {D_VIT}, R_VEC);
+    add(v, p + "norm2.weight", {D_VIT}, R_VEC);
+    add(v, p + "norm2.bias", {D_VIT}, R_VEC);
+    add(v, p + "mlp.fc1.weight", {D_MLP, D_VIT}, R_LINEAR);
+    add(v, p + "mlp.fc1.bias", {D_MLP}, R_VEC);
+    add(v, p + "mlp.fc2.weight", {D_VIT, D_MLP}, R_LINEAR);
+    add(v, p + "mlp.fc2.bias", {D_VIT}, R_VEC);
+  }
+  add(v, vp + "norm.weight", {D_VIT}, R_UNUSED);
+  add(v, vp + "norm.bias", {D_VIT}, R_UNUSED);
+  add(v, vp + "head.weight", {1000, D_VIT}, R_UNUSED);
+  add(v, vp + "head.bias", {1000}, R_UNUSED);
+  for (int n = 3; n <= 4; ++n) {
+    const std::string p = "pretrained.act_postprocess" + std::to_string(n) + ".";
+    add(v, p + "0.project.0.weight", {D_VIT, 2 * D_VIT}, R_LINEAR);
+    add(v, p + "0.project.0.bias", {D_VIT}, R_VEC);
+    add(v, p + "3.weight", {D_VIT, D_VIT, 1, 1}, R_CONV);
+    add(v, p + "3.bias", {D_VIT}, R_VEC);
+    if (n == 4) {
+      add(v, p + "4.weight", {D_VIT, D_VIT, 3, 3}, R_CONV);
+      add(v, p + "4.bias", {D_VIT}, R_VEC);
+    }
+  }
+  const int rn_in[4] = {256, 512, 768, 768};
+  for (int i = 1; i <= 4; ++i) add(v, "scratch.layer" + std::to_string(i) + "_rn.weight", {FEAT, rn_in[i - 1], 3, 3}, R_CONV);
+  for (int i = 1; i <= 4; ++i) {
+    const std::string p = "scratch.refinenet" + std::to_string(i) + ".";
+    add(v, p + "out_conv.weight", {FEAT, FEAT, 1, 1}, R_CONV);
+    add(v, p + "out_conv.bias", {FEAT}, R_VEC);
+    for (int u = 1; u <= 2; ++u)
+      for (int c = 1; c <= 2; ++c) {
+        const bool unused = (i == 4 && u == 1);  // blocks.py:329-333: resConfUnit1 needs two inputs
+        const std::string q = p + "resConfUnit" + std::to_string(u) + ".conv" + std::to_string(c) + ".";
+        add(v, q + "weight", {FEAT, FEAT, 3, 3}, unused ? R_UNUSED : R_CONV);
+        add(v, q + "bias", {FEAT}, unused ? R_UNUSED : R_VEC);
+      }
+  }
+  add(v, "scratch.output_conv.0.weight", {FEAT / 2, FEAT, 3, 3}, R_CONV);
+  add(v, "scratch.output_conv.0.bias", {FEAT / 2}, R_VEC);
+  add(v, "scratch.output_conv.2.weight", {32, FEAT / 2, 3, 3}, R_CONV);
+  add(v, "scratch.output_conv.2.bias", {32}, R_VEC);
+  add(v, "scratch.output_conv.4.weight", {C, 32, 1, 1}, R_HEAD4);
+  add(v, "scratch.output_conv.4.bias", {C}, R_VEC);
+  return v;
+}
+
+inline size_t numel(const std::vector<int64_t>& s) {
+  size_t n = 1;
+  for (auto d : s) n *= (size_t)d;
+  return n;
+}
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+constexpr int STEM_K = 192;  // 7*7*3 = 147 padded to 3 k-tiles of 64
+
+size_t packed_entry_bytes(const Spec& s) {
+  switch (s.role) {
+    case R_STDCONV:
+      if (s.shape[3] == 7) return (size_t)s.shape[0] * STEM_K * 2;
+      return numel(s.shape) * 2;
+    case R_CONV:
+    case R_LINEAR: return numel(s.shape) * 2;
+    case R_VEC:
+    case R_HEAD4: return numel(s.shape) * 4;
+    default: return 0;
+  }
+}
+
+struct Buf {  // arena slice
+  size_t off = 0, bytes = 0;
+};
+
+struct TapInfo {
+  const void* ptr;
+  int64_t shape[4];
+  bool fp32;
+};
+
+}  // namespace
+
+struct dptx_engine {
+  dptx_config cfg;
+  std::vector<Spec> spec;
+  std::unordered_map<std::string, size_t> spec_index;
+  std::unordered_map<std::string, size_t> packed_off;  // byte offset inside the blob
+  size_t packed_bytes = 0;
+  std::map<std::string, std::vector<float>> staged;  // fp32 tensors loaded so far
+  std::vector<uint8_t> host_blob;
+  bool finalized = false;  // host blob valid
+  bool device_ready = false;
+  char* d_blob = nullptr;
+  char* d_arena = nullptr;
+  size_t arena_bytes = 0;
+  std::string err;
+  std::map<std::string, TapInfo> taps;
+  bool taps_on = false;
+  float* d_tok_taps = nullptr;  // [13][B*577*768] fp32 copies of the token stream (taps_on)
+  int64_t launches = 0;
+  double exec_macs = 0.0;
+  int last_batch = 0;
+
+  // arena slices
+  Buf col, sraw, stem, S[3], T1, T2, PA, PB, DS, part[4], X, Hn, QKV, AO, F1, R3, R4, L3, T4, L4, clsb, lrn[4], tA, tB,
+      tC, P[4], H0, H0U, H1;
+
+  int fail(int code, const std::string& m) {
+    err = m;
+    return code;
+  }
+  const void* w(const std::string& key) const { return d_blob + packed_off.at(key); }
+  const float* f(const std::string& key) const { return (const float*)(d_blob + packed_off.at(key)); }
+  char* a(const Buf& b) const { return d_arena + b.off; }
+};
+
+namespace {
+
+#define HIPCHK(e, call)                                                                   \
+  do {                                                                                    \
+    hipError_t _r = (call);                                                               \
+    if (_r != hipSuccess) return (e)->fail(DPTX_E_HIP, std::string(#call) + ": " + hipGetErrorString(_r)); \
+  } while (0)
+
+void plan_arena(dptx_engine* e) {
+  const size_t B = (size_t)e->cfg.max_batch;
+  size_t off = 0;
+  auto take = [&](Buf& b, size_t elems, size_t esz) {
+    b.off = off;
+    b.bytes = align_up(elems * esz, 256);
+    off += b.bytes;
+  };
+  take(e->col, B * 36864 * STEM_K, 2);
+  take(e->sraw, B * 36864 * 64, 2);
+  take(e->stem, B * 9216 * 64, 2);
+  take(e->S[0], B * 9216 * 256, 2);
+  take(e->S[1], B * 2304 * 512, 2);
+  take(e->S[2], B * 576 * 1024, 2);
+  take(e->T1, B * 9216 * 128, 2);  // largest conv1 output: stage1 block0 (128 ch @96^2)
+  take(e->T2, B * 9216 * 64, 2);   // largest conv2 output: stage0 (64 ch @96^2)
+  take(e->PA, B * 9216 * 256, 2);
+  take(e->PB, B * 9216 * 256, 2);
+  take(e->DS, B * 9216 * 256, 2);
+  for (int i = 0; i < 4; ++i) take(e->part[i], B * 144 * 64, 4);
+  take(e->X, B * S_TOK * D_VIT, 4);
+  take(e->Hn, B * S_TOK * D_VIT, 2);
+  take(e->QKV, B * S_TOK * 3 * D_VIT, 2);
+  take(e->AO, B * S_TOK * D_VIT, 2);
+  take(e->F1, B * S_TOK * D_MLP, 2);
+  take(e->R3, B * 576 * D_VIT, 2);
+  take(e->R4, B * 576 * D_VIT, 2);
+  take(e->L3, B * 576 * D_VIT, 2);
+  take(e->T4, B * 576 * D_VIT, 2);
+  take(e->L4, B * 144 * D_VIT, 2);
+  take(e->clsb, B * D_VIT, 4);
+  const size_t rn_px[4] = {9216, 2304, 576, 144};
+  for (int i = 0; i < 4; ++i) take(e->lrn[i], B * rn_px[i] * FEAT, 2);
+  take(e->tA, B * 9216 * FEAT, 2);
+  take(e->tB, B * 9216 * FEAT, 2);
+  take(e->tC, B * 9216 * FEAT, 2);
+  const size_t p_px[4] = {36864, 9216, 2304, 576};  // P[0]=path_1 (192^2) ... P[3]=path_4 (24^2)
+  for (int i = 0; i < 4; ++i) take(e->P[i], B * p_px[i] * FEAT, 2);
+  take(e->H0, B * 36864 * 128, 2);
+  take(e->H0U, B * 147456 * 128, 2);
+  take(e->H1, B * 147456 * 32, 2);
+  e->arena_bytes = off;
+}
+
+// ------------------------------------------------------------------------------- packing
+int pack_host(dptx_engine* e) {
+  std::string missing;
+  for (const auto& s : e->spec)
+    if (s.role != R_UNUSED && !e->staged.count(s.key)) missing += (missing.empty() ? "" : ", ") + s.key;
+  if (!missing.empty()) return e->fail(DPTX_E_KEY, "missing tensors (strict load): " + missing);
+  e->host_blob.assign(e->packed_bytes, 0);
+  const bool bf = e->cfg.dtype == DPTX_DTYPE_BF16;
+  auto cvt = [&](float x) { return bf ? f32_to_bf16(x) : f32_to_fp16(x); };
+  for (const auto& s : e->spec) {
+    if (s.role == R_UNUSED) continue;
+    const std::vector<float>& src = e->staged.at(s.key);
+    uint8_t* dst = e->host_blob.data() + e->packed_off.at(s.key);
+    if (s.role == R_VEC || s.role == R_HEAD4) {
+      memcpy(dst, src.data(), src.size() * 4);
+      continue;
+    }
+    uint16_t* d16 = (uint16_t*)dst;
+    if (s.role == R_LINEAR) {
+      for (size_t i = 0; i < src.size(); ++i) d16[i] = cvt(src[i]);
+      continue;
+    }
+    // convolution OIHW -> [O][kh][kw][I]; StdConv2dSame weights are standardised first
+    const int O = (int)s.shape[0], I = (int)s.shape[1], KH = (int)s.shape[2], KW = (int)s.shape[3];
+    const size_t per_o = (size_t)I * KH * KW;
+    const bool stem = (KH == 7);
+    const size_t out_k = stem ? STEM_K : per_o;
+    for (int o = 0; o < O; ++o) {
+      const float* wo = src.data() + (size_t)o * per_o;
+      double mean = 0.0, scale = 1.0;
+      if (s.role == R_STDCONV) {
+        double sum = 0.0;
+        for (size_t i = 0; i < per_o; ++i) sum += wo[i];
+        mean = sum / (double)per_o;
+        double var = 0.0;
+        for (size_t i = 0; i < per_o; ++i) { const double t = wo[i] - mean; var += t * t; }
+        var /= (double)per_o;  // biased, as torch.std_mean(unbiased=False)
+        scale = e->cfg.ws_form == 0 ? 1.0 / (std::sqrt(var) + (double)e->cfg.ws_eps)
+                                    : 1.0 / std::sqrt(var + (double)e->cfg.ws_eps);
+      }
+      for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx)
+          for (int i = 0; i < I; ++i) {
+            const double wv = ((double)wo[((size_t)i * KH + ky) * KW + kx] - mean) * scale;
+            d16[(size_t)o * out_k + ((size_t)ky * KW + kx) * I + i] = cvt((float)wv);
+          }
+    }
+  }
+  e->finalized = true;
+  return DPTX_OK;
+}
+
+// ------------------------------------------------------------------------------ schedule
+struct Run {
+  dptx_engine* e;
+  int B;
+  hipStream_t st;
+  int dt;
+  hipError_t err = hipSuccess;
+  const char* where = "";
+
+  void chk(hipError_t r, const char* w) {
+    if (err == hipSuccess && r != hipSuccess) { err = r; where = w; }
+    e->launches++;
+  }
+  void tap(const char* name, const void* p, int64_t h, int64_t w, int64_t c, bool fp32 = false) {
+    e->taps[name] = TapInfo{p, {B, h, w, c}, fp32};
+  }
+
+  // NHWC convolution as implicit GEMM
+  void conv(const void* in, int Hin, int Win, int Cin, const std::string& wkey, int ksz, int stride, int pad_t, int pad_l,
+            int Hout, int Wout, int Cout, void* out, const float* bias, int act, int a_relu, const void* R1 = nullptr,
+            const void* R2 = nullptr) {
+    GemmParams p{};
+    p.A = in; p.W = e->w(wkey); p.C = out; p.bias = bias; p.R1 = R1; p.R2 = R2;
+    p.M = B * Hout * Wout; p.N = Cout; p.K = ksz * ksz * Cin; p.ldw = p.K;
+    p.a_rpi = Hout * Wout; p.Wout = Wout; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.a_pix_stride = Cin;
+    p.a_img_stride = (long long)Hin * Win * Cin; p.a_off = 0;
+    p.ksz = ksz; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+    p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = Cout;
+    p.act = act; p.a_relu = a_relu;
+    e->exec_macs += (double)p.M / B * p.N * p.K;
+    chk(launch_gemm(dt, p, st), wkey.c_str());
+  }
+
+  void gn_stats(const void* X, float* part, int HW, int C) { chk(launch_gn_stats(dt, X, part, B, HW, C, st), "gn_stats"); }
+  void gn_apply(void* X, const std::string& nkey, float* part, int HW, int C, int relu, const void* R = nullptr,
+                const std::string& rkey = "", const float* rpart = nullptr) {
+    GnParams g{};
+    g.X = X; g.Y = X; g.gamma = e->f(nkey + ".weight"); g.beta = e->f(nkey + ".bias"); g.partial = part;
+    g.R = R;
+    if (!rkey.empty()) { g.r_gamma = e->f(rkey + ".weight"); g.r_beta = e->f(rkey + ".bias"); g.r_partial = rpart; }
+    g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = 1e-5f;
+    chk(launch_gn_apply(dt, g, st), nkey.c_str());
+  }
+
+  // RCU (blocks.py:263-286): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
+  void rcu(const std::string& p, const void* x, int H, void* tmp, void* out, const void* extra) {
+    conv(x, H, H, FEAT, p + "conv1.weight", 3, 1, 1, 1, H, H, FEAT, tmp, e->f(p + "conv1.bias"), /*act*/ 1, /*a_relu*/ 1);
+    conv(tmp, H, H, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, H, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra);
+  }
+
+  int forward(const float* x, float* y);
+};
+
+int Run::forward(const float* x, float* y) {
+  dptx_engine* E = e;
+  E->taps.clear();
+  E->launches = 0;
+  E->exec_macs = 0.0;
+  const std::string vp = "pretrained.model.";
+  const std::string bp = vp + "patch_embed.backbone.";
+  float* part0 = (float*)E->a(E->part[0]);
+  float* part1 = (float*)E->a(E->part[1]);
+  float* part2 = (float*)E->a(E->part[2]);
+  float* part3 = (float*)E->a(E->part[3]);
+
+  // ---- stem: conv7x7 s2 SAME (im2col + GEMM) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
+  chk(launch_im2col_stem(dt, x, E->a(E->col), B, IMG, IMG, st), "im2col_stem");
+  {
+    GemmParams p;
+    gemm_params_dense(p, B * 36864, 64, STEM_K);
+    p.A = E->a(E->col); p.W = E->w(bp + "stem.conv.weight"); p.C = E->a(E->sraw);
+    E->exec_macs += 36864.0 * 64 * STEM_K;
+    chk(launch_gemm(dt, p, st), "stem.conv");
+  }
+  gn_stats(E->a(E->sraw), part0, 36864, 64);
+  chk(launch_gn_relu_maxpool(dt, E->a(E->sraw), E->a(E->stem), E->f(bp + "stem.norm.weight"), E->f(bp + "stem.norm.bias"),
+                             part0, B, 192, 192, 64, 1e-5f, st),
+      "stem.pool");
+  tap("stem", E->a(E->stem), 96, 96, 64);
+
+  // ---- ResNetV2 stages (3,4,9) non-preact bottlenecks -----------------------------------
+  const void* cur = E->a(E->stem);
+  int H = 96, cin = 64;
+  for (int s = 0; s < 3; ++s) {
+    const int cout = STAGE_OUT[s], mid = cout / 4;
+    for (int b = 0; b < STAGE_DEPTH[s]; ++b) {
+      const std::string p = bp + "stages." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+      const int stride = (b == 0) ? STAGE_STRIDE[s] : 1;
+      const int Ho = H / stride;
+      void* out = (b == STAGE_DEPTH[s] - 1) ? (void*)E->a(E->S[s]) : (void*)((b & 1) ? E->a(E->PB) : E->a(E->PA));
+      if (b == 0) {
+        conv(cur, H, H, cin, p + "downsample.conv.weight", 1, stride, 0, 0, Ho, Ho, cout, E->a(E->DS), nullptr, 0, 0);
+        gn_stats(E->a(E->DS), part3, Ho * Ho, cout);
+      }
+      conv(cur, H, H, cin, p + "conv1.weight", 1, 1, 0, 0, H, H, mid, E->a(E->T1), nullptr, 0, 0);
+      gn_stats(E->a(E->T1), part0, H * H, mid);
+      gn_apply(E->a(E->T1), p + "norm1", part0, H * H, mid, 1);
+      // 3x3, stride on conv2 (V1.5); TF-SAME: s1 -> pad (1,1); s2 on even H -> pad (0,1)
+      const int pad = (stride == 1) ? 1 : 0;
+      conv(E->a(E->T1), H, H, mid, p + "conv2.weight", 3, stride, pad, pad, Ho, Ho, mid, E->a(E->T2), nullptr, 0, 0);
+      gn_stats(E->a(E->T2), part1, Ho * Ho, mid);
+      gn_apply(E->a(E->T2), p + "norm2", part1, Ho * Ho, mid, 1);
+      conv(E->a(E->T2), Ho, Ho, mid, p + "conv3.weight", 1, 1, 0, 0, Ho, Ho, cout, out, nullptr, 0, 0);
+      gn_stats(out, part2, Ho * Ho, cout);
+      if (b == 0)
+        gn_apply(out, p + "norm3", part2, Ho * Ho, cout, 1, E->a(E->DS), p + "downsample.norm", part3);
+      else
+        gn_apply(out, p + "norm3", part2, Ho * Ho, cout, 1, cur);
+      cur = out;
+      H = Ho;
+      cin = cout;
+    }
+    const char* names[3] = {"s0", "s1", "s2"};
+    tap(names[s], cur, H, H, cout);
+  }
+
+  // ---- tokens: 1x1 proj + bias + pos_embed -> fp32 stream X[b*577 + 1 + p]; cls rows ----
+  float* X = (float*)E->a(E->X);
+  {
+    GemmParams p;
+    gemm_params_dense(p, B * 576, D_VIT, 1024);
+    p.A = E->a(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
+    p.bias = E->f(vp + "patch_embed.proj.bias");
+    p.c_rpi = 576; p.c_img_rows = S_TOK; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
+    p.R2 = E->f(vp + "pos_embed"); p.r2_bcast = 1; p.r2_fp32 = 1;
+    E->exec_macs += 576.0 * D_VIT * 1024;
+    chk(launch_gemm(dt, p, st), "patch_embed.proj");
+  }
+  chk(launch_cls_rows(E->f(vp + "cls_token"), E->f(vp + "pos_embed"), X, B, S_TOK, D_VIT, st), "cls_rows");
+  const int M = B * S_TOK;
+  const size_t tok_elems = (size_t)M * D_VIT;
+  auto tok_tap = [&](int idx, const char* name) {
+    if (!E->taps_on) return;
+    float* dst = E->d_tok_taps + (size_t)idx * (size_t)E->cfg.max_batch * S_TOK * D_VIT;
+    if (err == hipSuccess) err = hipMemcpyAsync(dst, X, tok_elems * 4, hipMemcpyDeviceToDevice, st);
+    E->taps[name] = TapInfo{dst, {B, S_TOK, D_VIT, 1}, true};
+  };
+  tok_tap(0, "tok0");
+
+  auto dense = [&](const void* A, int a_fp32, const std::string& wkey, int N, int K, void* C, int c_fp32, const float* bias,
+                   int act, const void* R1, int r1_fp32) {
+    GemmParams p;
+    gemm_params_dense(p, M, N, K);
+    p.A = A; p.a_fp32 = a_fp32; p.W = E->w(wkey); p.C = C; p.c_fp32 = c_fp32; p.bias = bias; p.act = act;
+    p.R1 = R1; p.r1_fp32 = r1_fp32;
+    E->exec_macs += (double)S_TOK * N * K;
+    chk(launch_gemm(dt, p, st), wkey.c_str());
+  };
+
+  // ProjectReadout + reassemble for hook n (3 -> block 8, 4 -> block 11)
+  auto readout = [&](int n) {
+    const std::string pp = "pretrained.act_postprocess" + std::to_string(n) + ".";
+    float* clsb = (float*)E->a(E->clsb);
+    chk(launch_readout_cls(dt, X, (long long)S_TOK * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT, D_VIT,
+                           E->f(pp + "0.project.0.bias"), clsb, B, D_VIT, D_VIT, st),
+        "readout_cls");
+    E->exec_macs += (double)D_VIT * D_VIT;  // per image
+    void* R = (n == 3) ? E->a(E->R3) : E->a(E->R4);
+    GemmParams p{};
+    p.A = X; p.a_fp32 = 1; p.W = E->w(pp + "0.project.0.weight"); p.ldw = 2 * D_VIT; p.C = R;
+    p.M = B * 576; p.N = D_VIT; p.K = D_VIT;
+    p.a_rpi = 576; p.Wout = 576; p.Hin = 1; p.Win = 576; p.Cin = D_VIT; p.a_pix_stride = D_VIT;
+    p.a_img_stride = (long long)S_TOK * D_VIT; p.a_off = D_VIT;  // skip the cls row
+    p.ksz = 1; p.stride = 1;
+    p.c_rpi = 576; p.c_img_rows = 576; p.c_row_off = 0; p.ldc = D_VIT;
+    p.bias = clsb; p.bias_per_img = 1; p.act = 2;
+    E->exec_macs += 576.0 * D_VIT * D_VIT;
+    chk(launch_gemm(dt, p, st), "readout");
+    if (n == 3) {
+      conv(R, 24, 24, D_VIT, pp + "3.weight", 1, 1, 0, 0, 24, 24, D_VIT, E->a(E->L3), E->f(pp + "3.bias"), 0, 0);
+      tap("l3", E->a(E->L3), 24, 24, D_VIT);
+    } else {
+      conv(R, 24, 24, D_VIT, pp + "3.weight", 1, 1, 0, 0, 24, 24, D_VIT, E->a(E->T4), E->f(pp + "3.bias"), 0, 0);
+      conv(E->a(E->T4), 24, 24, D_VIT, pp + "4.weight", 3, 2, 1, 1, 12, 12, D_VIT, E->a(E->L4), E->f(pp + "4.bias"), 0, 0);
+      tap("l4", E->a(E->L4), 12, 12, D_VIT);
+    }
+  };
+
+  // ---- 12 transformer blocks (timm Block; LN eps 1e-6) -----------------------------------
+  for (int l = 0; l < 12; ++l) {
+    const std::string p = vp + "blocks." + std::to_string(l) + ".";
+    chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, st), "ln1");
+    dense(E->a(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, E->a(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0);
+    chk(launch_attention(dt, E->a(E->QKV), E->a(E->AO), B, S_TOK, N_HEADS, st), "attention");
+    E->exec_macs += 2.0 * N_HEADS * (double)S_TOK * S_TOK * 64;
+    dense(E->a(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1);
+    chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, st), "ln2");
+    dense(E->a(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, E->a(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0);
+    dense(E->a(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1);
+    {
+      char nm[16];
+      snprintf(nm, sizeof nm, "blk%d", l);
+      tok_tap(l + 1, nm);
+    }
+    if (l == 8) readout(3);
+    if (l == 11) readout(4);
+  }
+  // timm's final model.norm is dead compute in the reference (vit.py:153, result discarded :64)
+
+  // ---- scratch.layerN_rn (3x3, no bias) ---------------------------------------------------
+  const void* rn_in[4] = {E->a(E->S[0]), E->a(E->S[1]), E->a(E->L3), E->a(E->L4)};
+  const int rn_h[4] = {96, 48, 24, 12};
+  const int rn_c[4] = {256, 512, 768, 768};
+  const char* rn_names[4] = {"l1_rn", "l2_rn", "l3_rn", "l4_rn"};
+  for (int i = 0; i < 4; ++i) {
+    conv(rn_in[i], rn_h[i], rn_h[i], rn_c[i], "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
+         rn_h[i], FEAT, E->a(E->lrn[i]), nullptr, 0, 0);
+    tap(rn_names[i], E->a(E->lrn[i]), rn_h[i], rn_h[i], FEAT);
+  }
+
+  // ---- RefineNet fusion 4 -> 1 (blocks.py:320-341).  out_conv (1x1) is applied BEFORE the x2
+  // bilinear upsample: both are linear and the interpolation weights sum to 1, so
+  // out_conv(up(x)) == up(out_conv(x)) exactly in real arithmetic, at a quarter of the MACs.
+  const void* path = nullptr;
+  const char* p_names[4] = {"p1", "p2", "p3", "p4"};
+  for (int i = 4; i >= 1; --i) {
+    const std::string p = "scratch.refinenet" + std::to_string(i) + ".";
+    const int h = rn_h[i - 1];
+    const void* sum;
+    if (i == 4) {
+      sum = E->a(E->lrn[3]);
+    } else {
+      rcu(p + "resConfUnit1.", E->a(E->lrn[i - 1]), h, E->a(E->tA), E->a(E->tB), path);  // tB = path + RCU1(lrn)
+      sum = E->a(E->tB);
+    }
+    rcu(p + "resConfUnit2.", sum, h, E->a(E->tA), E->a(E->tC), nullptr);
+    conv(E->a(E->tC), h, h, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, h, FEAT, E->a(E->tA), E->f(p + "out_conv.bias"), 0, 0);
+    chk(launch_upsample2x(dt, E->a(E->tA), E->a(E->P[i - 1]), B, h, h, FEAT, st), "fusion.up");
+    path = E->a(E->P[i - 1]);
+    tap(p_names[i - 1], path, 2 * h, 2 * h, FEAT);
+  }
+
+  // ---- head (dpt_depth.py:91-99) ----------------------------------------------------------
+  const std::string oc = "scratch.output_conv.";
+  conv(path, 192, 192, FEAT, oc + "0.weight", 3, 1, 1, 1, 192, 192, 128, E->a(E->H0), E->f(oc + "0.bias"), 0, 0);
+  tap("h0", E->a(E->H0), 192, 192, 128);
+  chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, 192, 192, 128, st), "head.up");
+  conv(E->a(E->H0U), 384, 384, 128, oc + "2.weight", 3, 1, 1, 1, 384, 384, 32, E->a(E->H1), E->f(oc + "2.bias"), 1, 0);
+  tap("h1", E->a(E->H1), 384, 384, 32);
+  chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), y, B, IMG * IMG, E->cfg.num_channels,
+                      E->cfg.non_negative, st),
+      "head.out");
+  E->exec_macs += 147456.0 * 32 * E->cfg.num_channels;
+  E->last_batch = B;
+  if (err != hipSuccess) return E->fail(DPTX_E_HIP, std::string("launch failed at ") + where + ": " + hipGetErrorString(err));
+  return DPTX_OK;
+}
+
+}  // namespace
+
+// =================================================================================== C ABI
+extern "C" {
+
+const char* dptx_version(void) { return "dptx 0.1.0 (gfx950)"; }
+
+void dptx_default_config(dptx_config* cfg) {
+  memset(cfg, 0, sizeof *cfg);
+  cfg->num_channels = 3;
+  cfg->max_batch = 32;
+  cfg->dtype = DPTX_DTYPE_BF16;
+  cfg->device_id = 0;
+  cfg->non_negative = 1;
+  cfg->ws_form = 0;
+  cfg->ws_eps = 1e-8f;
+}
+
+int dptx_create(dptx_handle* out, const dptx_config* cfg) {
+  if (!out || !cfg) return DPTX_E_INVALID;
+  *out = nullptr;
+  if ((cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 4096 ||
+      (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16) || (cfg->ws_form != 0 && cfg->ws_form != 1))
+    return DPTX_E_INVALID;
+  dptx_engine* e = new (std::nothrow) dptx_engine();
+  if (!e) return DPTX_E_ALLOC;
+  e->cfg = *cfg;
+  e->spec = build_spec(cfg->num_channels);
+  size_t off = 0;
+  for (size_t i = 0; i < e->spec.size(); ++i) {
+    e->spec_index[e->spec[i].key] = i;
+    const size_t b = packed_entry_bytes(e->spec[i]);
+    if (b) {
+      e->packed_off[e->spec[i].key] = off;
+      off += align_up(b, 256);
+    }
+  }
+  e->packed_bytes = off;
+  plan_arena(e);
+  if (cfg->device_id >= 0) {
+    int n = 0;
+    hipError_t r = hipGetDeviceCount(&n);
+    if (r != hipSuccess || cfg->device_id >= n) {
+      delete e;
+      return DPTX_E_NODEVICE;
+    }
+  }
+  *out = e;
+  return DPTX_OK;
+}
+
+void dptx_destroy(dptx_handle h) {
+  if (!h) return;
+  if (h->cfg.device_id >= 0) {
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->d_arena) (void)hipFree(h->d_arena);
+    if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
+  }
+  delete h;
+}
+
+const char* dptx_last_error(dptx_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int dptx_load_tensor(dptx_handle h, const char* ref_key, const float* host_fp32, const int64_t* shape, int32_t ndim) {
+  if (!h || !ref_key || !host_fp32 || !shape || ndim < 1) return DPTX_E_INVALID;
+  auto it = h->spec_index.find(ref_key);
+  if (it == h->spec_index.end()) return h->fail(DPTX_E_KEY, std::string("unexpected key: ") + ref_key);
+  const Spec& s = h->spec[it->second];
+  bool ok = (size_t)ndim == s.shape.size();
+  for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == s.shape[i];
+  if (!ok) return h->fail(DPTX_E_KEY, std::string("shape mismatch for ") + ref_key);
+  if (s.role == R_UNUSED) return DPTX_OK;
+  h->staged[s.key].assign(host_fp32, host_fp32 + numel(s.shape));
+  h->finalized = false;
+  h->device_ready = false;
+  return DPTX_OK;
+}
+
+static int ensure_device_memory(dptx_handle h) {
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (!h->d_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, h->packed_bytes));
+  if (!h->d_arena) HIPCHK(h, hipMalloc((void**)&h->d_arena, h->arena_bytes));
+  return DPTX_OK;
+}
+
+int dptx_finalize_weights(dptx_handle h) {
+  if (!h) return DPTX_E_INVALID;
+  int r = pack_host(h);
+  if (r != DPTX_OK) return r;
+  if (h->cfg.device_id < 0) return DPTX_OK;
+  r = ensure_device_memory(h);
+  if (r != DPTX_OK) return r;
+  HIPCHK(h, hipMemcpy(h->d_blob, h->host_blob.data(), h->packed_bytes, hipMemcpyHostToDevice));
+  h->device_ready = true;
+  h->staged.clear();  // fp32 staging copies are no longer needed
+  return DPTX_OK;
+}
+
+size_t dptx_packed_bytes(dptx_handle h) { return h ? h->packed_bytes : 0; }
+
+int dptx_export_packed_host(dptx_handle h, void* dst_host, size_t bytes) {
+  if (!h || !dst_host) return DPTX_E_INVALID;
+  if (!h->finalized) return h->fail(DPTX_E_INVALID, "export before dptx_finalize_weights");
+  if (bytes < h->packed_bytes) return h->fail(DPTX_E_INVALID, "export buffer too small");
+  memcpy(dst_host, h->host_blob.data(), h->packed_bytes);
+  return DPTX_OK;
+}
+
+int dptx_export_packed_device(dptx_handle h, void* dst_dev, size_t bytes, void* stream) {
+  if (!h || !dst_dev) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
+  if (!h->device_ready) return h->fail(DPTX_E_INVALID, "export before weights are on the device");
+  if (bytes < h->packed_bytes) return h->fail(DPTX_E_INVALID, "export buffer too small");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemcpyAsync(dst_dev, h->d_blob, h->packed_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return DPTX_OK;
+}
+
+int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, void* stream) {
+  if (!h || !src_dev) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
+  if (bytes != h->packed_bytes) return h->fail(DPTX_E_INVALID, "packed blob size mismatch (different config/build?)");
+  int r = ensure_device_memory(h);
+  if (r != DPTX_OK) return r;
+  HIPCHK(h, hipMemcpyAsync(h->d_blob, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  h->device_ready = true;
+  return DPTX_OK;
+}
+
+size_t dptx_workspace_bytes(dptx_handle h) { return h ? h->packed_bytes + h->arena_bytes : 0; }
+
+int dptx_enable_taps(dptx_handle h, int on) {
+  if (!h) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
+  if (on && !h->d_tok_taps) {
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipMalloc((void**)&h->d_tok_taps, (size_t)13 * h->cfg.max_batch * S_TOK * D_VIT * 4));
+  }
+  h->taps_on = on != 0;
+  return DPTX_OK;
+}
+
+int dptx_forward(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, int32_t batch, void* stream) {
+  if (!h || !x_dev || !y_dev) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "dptx_forward on a host-only handle");
+  if (!h->device_ready) return h->fail(DPTX_E_INVALID, "dptx_forward before weights were finalized/imported");
+  if (batch < 1 || batch > h->cfg.max_batch) return h->fail(DPTX_E_INVALID, "batch out of range [1, max_batch]");
+  if (x_dtype != DPTX_IO_FP32) return h->fail(DPTX_E_INVALID, "unsupported x_dtype");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  Run run{h, batch, (hipStream_t)stream, h->cfg.dtype};
+  return run.forward((const float*)x_dev, (float*)y_dev);
+}
+
+int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_floats, int64_t shape4[4]) {
+  if (!h || !name || !dst_host || !shape4) return DPTX_E_INVALID;
+  auto it = h->taps.find(name);
+  if (it == h->taps.end()) return h->fail(DPTX_E_KEY, std::string("unknown or unavailable tap: ") + name);
+  const TapInfo& t = it->second;
+  size_t n = 1;
+  for (int i = 0; i < 4; ++i) { shape4[i] = t.shape[i]; n *= (size_t)t.shape[i]; }
+  if (capacity_floats < n) return h->fail(DPTX_E_INVALID, "tap buffer too small");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipDeviceSynchronize());
+  if (t.fp32) {
+    HIPCHK(h, hipMemcpy(dst_host, t.ptr, n * 4, hipMemcpyDeviceToHost));
+  } else {
+    float* tmp = nullptr;
+    HIPCHK(h, hipMalloc((void**)&tmp, n * 4));
+    hipError_t r = launch_to_f32(h->cfg.dtype, t.ptr, tmp, n, nullptr);
+    if (r == hipSuccess) r = hipMemcpy(dst_host, tmp, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (r != hipSuccess) return h->fail(DPTX_E_HIP, hipGetErrorString(r));
+  }
+  return DPTX_OK;
+}
+
+int dptx_forward_info(dptx_handle h, int64_t* launches, double* algorithmic_macs, double* executed_macs) {
+  if (!h) return DPTX_E_INVALID;
+  if (launches) *launches = h->launches;
+  if (algorithmic_macs) *algorithmic_macs = h->cfg.num_channels == 3 ? 127.624e9 : 127.615e9;
+  if (executed_macs) *executed_macs = h->exec_macs;
+  return DPTX_OK;
+}
+
+// --------------------------------------------------------------------- op-level entry points
+int dptx_op_gemm(int32_t dtype, const void* A, const void* W, const float* bias, const void* R, void* C, int32_t M, int32_t N,
+                 int32_t K, int32_t act, int32_t a_fp32, int32_t c_fp32, int32_t r_fp32, void* stream) {
+  GemmParams p;
+  gemm_params_dense(p, M, N, K);
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.R1 = R; p.act = act; p.a_fp32 = a_fp32; p.c_fp32 = c_fp32; p.r1_fp32 = r_fp32;
+  return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias, const void* R, void* Y, int32_t B, int32_t H,
+                 int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
+                 int32_t Wo, int32_t a_relu, int32_t act, void* stream) {
+  GemmParams p{};
+  p.A = X; p.W = Wt; p.C = Y; p.bias = bias; p.R1 = R;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = ksize * ksize * Cin; p.ldw = p.K;
+  p.a_rpi = Ho * Wo; p.Wout = Wo; p.Hin = H; p.Win = W; p.Cin = Cin; p.a_pix_stride = Cin;
+  p.a_img_stride = (long long)H * W * Cin;
+  p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act; p.a_relu = a_relu;
+  return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_attention(int32_t dtype, const void* qkv, void* out, int32_t B, int32_t S, int32_t heads, void* stream) {
+  return launch_attention(dtype, qkv, out, B, S, heads, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta, void* y, int32_t M, int32_t C,
+                      float eps, void* stream) {
+  return launch_layernorm(dtype, x, gamma, beta, y, M, C, eps, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const float* beta, const void* R, void* Y, int32_t B,
+                      int32_t HW, int32_t C, int32_t relu, float eps, void* scratch_f32, void* stream) {
+  hipError_t r = launch_gn_stats(dtype, X, (float*)scratch_f32, B, HW, C, (hipStream_t)stream);
+  if (r != hipSuccess) return DPTX_E_HIP;
+  GnParams g{};
+  g.X = X; g.Y = Y; g.gamma = gamma; g.beta = beta; g.partial = (float*)scratch_f32; g.R = R;
+  g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = eps;
+  return launch_gn_apply(dtype, g, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_upsample2x(int32_t dtype, const void* X, void* Y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  return launch_upsample2x(dtype, X, Y, B, H, W, C, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+}  // extern "C"

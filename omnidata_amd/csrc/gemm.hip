@@ -1,0 +1,328 @@
+// gemm.hip -- implicit-GEMM MFMA kernel for every linear / 1x1 / 3x3 / 7x7(im2col'd) layer of
+// DPT-Hybrid (SURVEY.md A.6 lists the 44 unique shapes).  gfx950 only.
+//
+//   C[M,N] = epilogue( gatherA[M,K] * W[N,K]^T )
+//
+// * v_mfma_f32_32x32x16_{bf16,f16}: a wave owns a (TM*32) x (TN*32) accumulator block.
+// * BK = 64: one k-tile of A / W is [rows][64] 16-bit = 128 B per row in LDS, 16-B chunks
+//   XOR-swizzled with ((row>>1)&7) so that the ds_read_b128 fragment reads (16 distinct rows
+//   per lane group, same k chunk) are bank-conflict free; ds_write_b128 of a staged row hits 8
+//   distinct chunks.
+// * register-staged double buffering: global loads of tile t+1 are issued before the MFMAs of
+//   tile t and written to the other LDS buffer after them; one barrier per k-tile.
+// * A is gathered as NHWC conv taps (zero outside the image), so dense GEMM, strided 1x1 and
+//   kxk convolutions share the loader; optional ReLU / fp32->16-bit conversion while staging.
+// * epilogue: accumulators -> LDS fp32 tile -> coalesced 16-B rows with fused bias, ReLU /
+//   erf-GELU, up to two residuals (16-bit or fp32, one may broadcast over images), 16-bit or
+//   fp32 output, optional row remap (token rows skip the cls slot).
+// * 1-D grid, XCD-aware bijective remap; n-tile fastest so the blocks of one XCD re-use the
+//   same A rows out of that XCD's L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace dptx {
+
+constexpr int BK = 64;
+
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_FP32>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+  static_assert(TM >= 1 && TN >= 1, "tile");
+  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+  constexpr int A_REGS = A_FP32 ? 2 : 1;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int CT_PITCH = BN + 4;  // floats
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tiles_n = p.N / BN;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int n0 = (wg % tiles_n) * BN;
+  const int m0 = (wg / tiles_n) * BM;
+
+  // ---- loader state -------------------------------------------------------------------
+  const int kc = tid & 7;   // 16-B chunk (8 elements) inside the 64-wide k tile
+  const int r0 = tid >> 3;  // 0..31
+  int a_iy0[A_PASSES], a_ix0[A_PASSES];
+  long long a_base[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int img = mm / p.a_rpi;
+    const int rem = mm - img * p.a_rpi;
+    const int oy = rem / p.Wout;
+    const int ox = rem - oy * p.Wout;
+    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;  // invalid rows never pass the bounds test
+    a_ix0[i] = ox * p.stride - p.pad_l;
+    a_base[i] = (long long)img * p.a_img_stride + p.a_off + kc * 8;
+  }
+  const char* __restrict__ Ab = (const char*)p.A;
+  const uint16_t* __restrict__ Wb = (const uint16_t*)p.W;
+  long long w_off[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (long long)(n0 + r0 + 32 * j) * p.ldw + kc * 8;
+
+  uint4 ra[A_PASSES * A_REGS];
+  uint4 rb[B_PASSES];
+
+  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k tile being LOADED
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
+      const long long e = a_base[i] + ((long long)iy * p.Win + ix) * p.a_pix_stride + c0;
+      if constexpr (A_FP32) {
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (valid) {
+          const uint4* src = (const uint4*)(Ab + e * 4);
+          lo = src[0];
+          hi = src[1];
+        }
+        ra[2 * i] = lo;
+        ra[2 * i + 1] = hi;
+      } else {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (valid) v = *(const uint4*)(Ab + e * 2);
+        ra[i] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) rb[j] = *(const uint4*)(Wb + w_off[j] + k0);
+    // advance tap bookkeeping to the next tile
+    c0 += BK;
+    if (c0 >= p.Cin) {
+      c0 = 0;
+      if (++kx == p.ksz) { kx = 0; ++ky; }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    char* sb = sa + BM * 128;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int row = r0 + 32 * i;
+      uint4 v;
+      if constexpr (A_FP32) {
+        const uint4 lo = ra[2 * i], hi = ra[2 * i + 1];
+        v.x = T16<DT>::pack2(__uint_as_float(lo.x), __uint_as_float(lo.y));
+        v.y = T16<DT>::pack2(__uint_as_float(lo.z), __uint_as_float(lo.w));
+        v.z = T16<DT>::pack2(__uint_as_float(hi.x), __uint_as_float(hi.y));
+        v.w = T16<DT>::pack2(__uint_as_float(hi.z), __uint_as_float(hi.w));
+      } else {
+        v = ra[i];
+      }
+      if (p.a_relu) v = relu8(v);
+      *(uint4*)(sa + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const int row = r0 + 32 * j;
+      *(uint4*)(sb + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rb[j];
+    }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  auto compute_tile = [&](int buf) {
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sb = sa + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int chunk = 2 * ks + lh;
+      uint4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + lr;
+        af[i] = *(const uint4*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + lr;
+        bf[j] = *(const uint4*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = T16<DT>::mfma32(af[i], bf[j], acc[i][j]);
+    }
+  };
+
+  // ---- main loop ----------------------------------------------------------------------
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1) < nk;
+    if (more) load_tile((kt + 1) * BK);
+    compute_tile(kt & 1);
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS fp32 tile -> coalesced rows ------------------------
+  float* ct = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int nl = wn * (TN * 32) + j * 32 + lr;
+        ct[ml * CT_PITCH + nl] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  constexpr int NCH = BN / 8;      // 8-column chunks per tile row
+  constexpr int RPP = 256 / NCH;   // tile rows per pass
+  const int cn = tid % NCH;
+  const int rr = tid / NCH;
+  const int n = n0 + cn * 8;
+  float bias_c[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias_c[e] = 0.f;
+  if (p.bias != nullptr && !p.bias_per_img) {
+    const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+    bias_c[0] = b0.x; bias_c[1] = b0.y; bias_c[2] = b0.z; bias_c[3] = b0.w;
+    bias_c[4] = b1.x; bias_c[5] = b1.y; bias_c[6] = b1.z; bias_c[7] = b1.w;
+  }
+#pragma unroll 2
+  for (int row = rr; row < BM; row += RPP) {
+    const int m = m0 + row;
+    if (m >= p.M) break;
+    const int img = m / p.c_rpi;
+    const int pp = m - img * p.c_rpi;
+    const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
+    float v[8];
+    {
+      const float4 x0 = *(const float4*)(ct + row * CT_PITCH + cn * 8);
+      const float4 x1 = *(const float4*)(ct + row * CT_PITCH + cn * 8 + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+      v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    }
+    if (p.bias_per_img) {
+      const float* bp = p.bias + (long long)img * p.N + n;
+      const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+      v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias_c[e];
+    }
+    if (p.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (p.act == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (p.R1 != nullptr) {
+      const long long off = crow * p.ldc + n;
+      if (p.r1_fp32) {
+        const float4 a0 = *(const float4*)((const float*)p.R1 + off), a1 = *(const float4*)((const float*)p.R1 + off + 4);
+        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
+        v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+      } else {
+        float f[8];
+        unpack8<DT>(*(const uint4*)((const uint16_t*)p.R1 + off), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += f[e];
+      }
+    }
+    if (p.R2 != nullptr) {
+      const long long r2row = p.r2_bcast ? (long long)(p.c_row_off + pp) : crow;
+      const long long off = r2row * p.ldc + n;
+      if (p.r2_fp32) {
+        const float4 a0 = *(const float4*)((const float*)p.R2 + off), a1 = *(const float4*)((const float*)p.R2 + off + 4);
+        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
+        v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+      } else {
+        float f[8];
+        unpack8<DT>(*(const uint4*)((const uint16_t*)p.R2 + off), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += f[e];
+      }
+    }
+    const long long coff = crow * p.ldc + n;
+    if (p.c_fp32) {
+      float* cp = (float*)p.C + coff;
+      *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      *(uint4*)((uint16_t*)p.C + coff) = pack8<DT>(v);
+    }
+  }
+}
+
+template <int BM, int BN>
+constexpr size_t gemm_smem_bytes() {
+  constexpr size_t stage = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t ct = (size_t)BM * (BN + 4) * 4;
+  return stage > ct ? stage : ct;
+}
+
+template <int DT, int BM, int BN, int WM_, int WN_>
+static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  constexpr size_t smem = gemm_smem_bytes<BM, BN>();
+  if (p.a_fp32) {
+    auto k = gemm_kernel<DT, BM, BN, WM_, WN_, true>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_done = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
+  } else {
+    auto k = gemm_kernel<DT, BM, BN, WM_, WN_, false>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_done = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
+  }
+  return hipGetLastError();
+}
+
+template <int DT>
+static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
+  // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
+  const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256, m64 = (p.M + 63) / 64;
+  if (p.N % 128 == 0 && m128 * (p.N / 128) >= 448) return launch_cfg<DT, 128, 128, 2, 2>(p, stream);
+  if (p.N == 32) return launch_cfg<DT, 256, 32, 4, 1>(p, stream);
+  if (p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, 256, 64, 4, 1>(p, stream);
+  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, 128, 64, 2, 2>(p, stream);
+  if (p.N % 64 == 0) return launch_cfg<DT, 64, 64, 2, 2>(p, stream);
+  (void)m64;
+  return hipErrorInvalidValue;
+}
+
+void gemm_params_dense(GemmParams& p, int M, int N, int K) {
+  p = GemmParams{};
+  p.M = M; p.N = N; p.K = K; p.ldw = K;
+  p.a_rpi = M > 0 ? M : 1; p.Wout = p.a_rpi; p.Hin = 1; p.Win = p.a_rpi; p.Cin = K; p.a_pix_stride = K;
+  p.a_img_stride = 0; p.a_off = 0; p.ksz = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0;
+  p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = N;
+}
+
+hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream) {
+  if (p.K % BK != 0 || p.Cin % BK != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 8 != 0) return hipErrorInvalidValue;
+  if (dtype == DT_BF16) return launch_dt<DT_BF16>(p, stream);
+  if (dtype == DT_FP16) return launch_dt<DT_FP16>(p, stream);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace dptx

@@ -1,0 +1,206 @@
+// misc.hip -- the HBM-bound glue kernels of the DPT-Hybrid forward: stem im2col, bilinear x2
+// (align_corners=True), the 32->C head projection writing NCHW fp32, cls-token rows, the cls
+// half of ProjectReadout, and an fp32 export for debug taps.
+#include "common.h"
+#include "kernels.h"
+
+namespace dptx {
+
+// ------------------------------------------------------------------------- stem im2col (7x7 s2)
+// x NCHW fp32 [B,3,H,W] -> col[B*Ho*Wo][192] 16-bit, k = (ky*7+kx)*3 + c (k >= 147 zero).
+// TF-SAME padding (timm StdConv2dSame): pad_total = (Ho-1)*2 + 7 - H, top/left = pad_total/2.
+template <int DT>
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ x, uint16_t* __restrict__ col, int B,
+                                                          int H, int W, int Ho, int Wo, int pt, int pl) {
+  const long long total = (long long)B * Ho * Wo * 24;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int j = (int)(i % 24);
+    const long long pix = i / 24;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const int b = (int)(pix / ((long long)Wo * Ho));
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = j * 8 + e;
+      float val = 0.f;
+      if (k < 147) {
+        const int tap = k / 3, c = k - tap * 3;
+        const int ky = tap / 7, kx = tap - ky * 7;
+        const int iy = 2 * oy + ky - pt, ix = 2 * ox + kx - pl;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) val = x[(((long long)b * 3 + c) * H + iy) * W + ix];
+      }
+      f[e] = val;
+    }
+    *(uint4*)(col + pix * 192 + j * 8) = pack8<DT>(f);
+  }
+}
+
+hipError_t launch_im2col_stem(int dtype, const float* x, void* col, int B, int H, int W, hipStream_t stream) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int pth = max((Ho - 1) * 2 + 7 - H, 0), ptw = max((Wo - 1) * 2 + 7 - W, 0);
+  const long long total = (long long)B * Ho * Wo * 24;
+  const int grid = (int)min((total + 255) / 256, (long long)8192);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(im2col_stem_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, x, (uint16_t*)col, B, H, W, Ho, Wo, pth / 2, ptw / 2);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(im2col_stem_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, x, (uint16_t*)col, B, H, W, Ho, Wo, pth / 2, ptw / 2);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ bilinear x2, align_corners
+// blocks.py:335-337 / dpt_depth.py:93: F.interpolate(scale_factor=2, mode="bilinear",
+// align_corners=True).  Index/lambda arithmetic follows ATen's fp32 formulation:
+// ratio = (in-1)/(out-1); src = ratio*dst; i0 = int(src); i1 = i0 + (i0 < in-1); l1 = src - i0.
+template <int DT>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y, int B, int H,
+                                                         int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W, cvec = C >> 3;
+  const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const long long total = (long long)B * Ho * Wo * cvec;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int v = (int)(i % cvec);
+    const long long pix = i / cvec;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const int b = (int)(pix / ((long long)Wo * Ho));
+    const float sy = ry * (float)oy, sx = rx * (float)ox;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const uint16_t* img = X + (long long)b * H * W * C + v * 8;
+    float a[8], bb[8], c[8], d[8], o[8];
+    unpack8<DT>(*(const uint4*)(img + ((long long)y0 * W + x0) * C), a);
+    unpack8<DT>(*(const uint4*)(img + ((long long)y0 * W + x1) * C), bb);
+    unpack8<DT>(*(const uint4*)(img + ((long long)y1 * W + x0) * C), c);
+    unpack8<DT>(*(const uint4*)(img + ((long long)y1 * W + x1) * C), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
+    *(uint4*)(Y + pix * C + v * 8) = pack8<DT>(o);
+  }
+}
+
+hipError_t launch_upsample2x(int dtype, const void* X, void* Y, int B, int H, int W, int C, hipStream_t stream) {
+  if (C % 8 != 0) return hipErrorInvalidValue;
+  const long long total = (long long)B * 4 * H * W * (C / 8);
+  const int grid = (int)min((total + 255) / 256, (long long)16384);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(upsample2x_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, (uint16_t*)Y, B, H, W, C);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(upsample2x_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, (uint16_t*)Y, B, H, W, C);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------- head: conv1x1 32->C (+ReLU)
+// dpt_depth.py:96-98.  X [B*HW][32] 16-bit (already ReLU'd) -> y NCHW fp32 [B][C][HW].
+template <int DT>
+__global__ __launch_bounds__(256) void head_out_kernel(const uint16_t* __restrict__ X, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int HW,
+                                                       int Cout, int relu) {
+  const long long total = (long long)B * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    float f[32];
+    const uint4* src = (const uint4*)(X + i * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) unpack8<DT>(src[q], f + 8 * q);
+    const long long b = i / HW, p = i - b * HW;
+    for (int c = 0; c < Cout; ++c) {
+      float acc = bias[c];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc += w[c * 32 + k] * f[k];
+      if (relu) acc = fmaxf(acc, 0.f);
+      y[(b * Cout + c) * HW + p] = acc;
+    }
+  }
+}
+
+hipError_t launch_head_out(int dtype, const void* X, const float* w, const float* b, float* y, int B, int HW, int Cout,
+                           int relu, hipStream_t stream) {
+  const long long total = (long long)B * HW;
+  const int grid = (int)min((total + 255) / 256, (long long)16384);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(head_out_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, w, b, y, B, HW, Cout, relu);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(head_out_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, w, b, y, B, HW, Cout, relu);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- cls rows
+// vit.py:141-147: x = cat(cls, patches) + pos_embed  ->  X[b*S + 0] = cls + pos[0]
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X, int B,
+                                int S, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  X[(long long)b * S * C + c] = cls[c] + pos[c];
+}
+hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, int S, int C, hipStream_t stream) {
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, cls, pos, X, B, S, C);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------- cls half of ProjectReadout (vit.py:44-47)
+// cat(tok, cls) @ W^T = tok @ W[:, :768]^T + cls @ W[:, 768:]^T : the second term is one
+// vector per image, computed here and consumed as a per-image bias by the token GEMM.
+// One wave per (image, output feature).
+template <int DT>
+__global__ __launch_bounds__(256) void readout_cls_kernel(const float* __restrict__ x, long long x_stride,
+                                                          const uint16_t* __restrict__ W, int ldw, int w_off,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int B, int N,
+                                                          int K) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= B * N) return;
+  const int b = idx / N, n = idx - b * N;
+  const float* xr = x + (long long)b * x_stride;
+  const uint16_t* wr = W + (long long)n * ldw + w_off;
+  float acc = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 xv = *(const float4*)(xr + k);
+    const uint2 wv = *(const uint2*)(wr + k);
+    acc += xv.x * T16<DT>::tof((uint16_t)(wv.x & 0xffffu)) + xv.y * T16<DT>::tof((uint16_t)(wv.x >> 16)) +
+           xv.z * T16<DT>::tof((uint16_t)(wv.y & 0xffffu)) + xv.w * T16<DT>::tof((uint16_t)(wv.y >> 16));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[idx] = acc + (bias ? bias[n] : 0.f);
+}
+
+hipError_t launch_readout_cls(int dtype, const float* x, long long x_stride, const void* W, int ldw, int w_off,
+                              const float* bias, float* out, int B, int N, int K, hipStream_t stream) {
+  if (K % 4 != 0 || w_off % 4 != 0 || ldw % 4 != 0) return hipErrorInvalidValue;
+  dim3 grid((B * N + 3) / 4);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(readout_cls_kernel<DT_BF16>, grid, dim3(256), 0, stream, x, x_stride, (const uint16_t*)W, ldw, w_off, bias, out, B, N, K);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(readout_cls_kernel<DT_FP16>, grid, dim3(256), 0, stream, x, x_stride, (const uint16_t*)W, ldw, w_off, bias, out, B, N, K);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ tap export
+template <int DT>
+__global__ void to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = T16<DT>::tof(src[i]);
+}
+hipError_t launch_to_f32(int dtype, const void* src, float* dst, size_t n, hipStream_t stream) {
+  const int grid = (int)min((n + 255) / 256, (size_t)8192);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(to_f32_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)src, dst, n);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(to_f32_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)src, dst, n);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace dptx

@@ -1,0 +1,271 @@
+// norm.hip -- LayerNorm (ViT blocks, eps 1e-6) and GroupNorm(32) (ResNetV2 stem/bottlenecks,
+// eps 1e-5) for the DPT-Hybrid forward.  HBM-bound kernels: 16-B vector accesses, fp32
+// statistics, wave-shuffle / fixed-order reductions (results are bit-reproducible run to run).
+#include "common.h"
+#include "kernels.h"
+
+namespace dptx {
+
+// ------------------------------------------------------------------------------ LayerNorm
+// x fp32 [M][C] (the fp32 residual stream) -> y 16-bit [M][C].  One wave per row; C = 768:
+// each lane owns 3 float4.  Two-pass (mean, then centred variance) in registers.
+template <int DT, int VPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, uint16_t* __restrict__ y,
+                                                        int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (long long)row * C;
+  float4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    v[j] = *(const float4*)(xr + (j * 64 + lane) * 4);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  uint16_t* yr = y + (long long)row * C;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int c0 = (j * 64 + lane) * 4;
+    const float4 g = *(const float4*)(gamma + c0), bb = *(const float4*)(beta + c0);
+    uint2 w;
+    w.x = T16<DT>::pack2((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y);
+    w.y = T16<DT>::pack2((v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w);
+    *(uint2*)(yr + c0) = w;
+  }
+}
+
+hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, void* y, int M, int C,
+                            float eps, hipStream_t stream) {
+  if (C != 768) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL((layernorm_kernel<DT_BF16, 3>), grid, dim3(256), 0, stream, x, gamma, beta, (uint16_t*)y, M, C, eps);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL((layernorm_kernel<DT_FP16, 3>), grid, dim3(256), 0, stream, x, gamma, beta, (uint16_t*)y, M, C, eps);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ GroupNorm
+// X NHWC 16-bit [B][HW][C], 32 groups of cpg = C/32 adjacent channels.
+// Stats pass: grid (chunks, B); a block reduces `pix` pixels x C channels to 32 x (sum, sumsq)
+// in a fixed order and writes partial[b][chunk][g][2].  The apply pass re-reduces the chunk
+// partials in double (fixed order) in its prologue, so no atomics and no finalize launch.
+constexpr int GN_G = 32;
+
+int gn_chunks(int HW) {
+  const int pix = HW <= 2304 ? 64 : 256;
+  return (HW + pix - 1) / pix;
+}
+static inline int gn_pix(int HW) { return HW <= 2304 ? 64 : 256; }
+
+template <int DT>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X, float* __restrict__ partial,
+                                                       int HW, int C, int pix) {
+  __shared__ float red[256 * 8];  // per thread: up to 4 (sum, sumsq) pairs
+  const int tid = threadIdx.x;
+  const int cvec = C >> 3;            // 16-B vectors per pixel (8..128)
+  const int cpg = C >> 5;             // channels per group (2..32)
+  const int spv = cpg >= 8 ? 1 : 8 / cpg;  // groups (slots) per vector: 1, 2 or 4
+  const int v = tid % cvec, p0 = tid / cvec, pstep = 256 / cvec;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int pbeg = chunk * pix;
+  const int pend = min(pbeg + pix, HW);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  const uint16_t* base = X + ((long long)b * HW) * C + v * 8;
+  for (int p = pbeg + p0; p < pend; p += pstep) {
+    float f[8];
+    unpack8<DT>(*(const uint4*)(base + (long long)p * C), f);
+    if (spv == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[0] += f[e]; q[0] += f[e] * f[e]; }
+    } else if (spv == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[0] += f[e]; q[0] += f[e] * f[e]; s[1] += f[4 + e]; q[1] += f[4 + e] * f[4 + e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += f[2 * e] + f[2 * e + 1]; q[e] += f[2 * e] * f[2 * e] + f[2 * e + 1] * f[2 * e + 1]; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[tid * 8 + 2 * e] = s[e]; red[tid * 8 + 2 * e + 1] = q[e]; }
+  __syncthreads();
+  if (tid < GN_G) {
+    // group g <- vectors [g*cpg/8, (g+1)*cpg/8) slot 0 (cpg >= 8) or vector g/spv slot g%spv
+    const int g = tid;
+    int v0, v1, slot;
+    if (spv == 1) { v0 = g * (cpg >> 3); v1 = v0 + (cpg >> 3); slot = 0; }
+    else { v0 = g / spv; v1 = v0 + 1; slot = g % spv; }
+    float ss = 0.f, qq = 0.f;
+    for (int pp = 0; pp < pstep; ++pp)
+      for (int vv = v0; vv < v1; ++vv) {
+        const int t = pp * cvec + vv;
+        ss += red[t * 8 + 2 * slot];
+        qq += red[t * 8 + 2 * slot + 1];
+      }
+    float* out = partial + (((long long)b * gridDim.x + chunk) * GN_G + g) * 2;
+    out[0] = ss;
+    out[1] = qq;
+  }
+}
+
+hipError_t launch_gn_stats(int dtype, const void* X, float* partial, int B, int HW, int C, hipStream_t stream) {
+  if (C % 64 != 0 || C > 1024 || (256 % (C / 8)) != 0) return hipErrorInvalidValue;
+  dim3 grid(gn_chunks(HW), B);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(gn_stats_kernel<DT_BF16>, grid, dim3(256), 0, stream, (const uint16_t*)X, partial, HW, C, gn_pix(HW));
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(gn_stats_kernel<DT_FP16>, grid, dim3(256), 0, stream, (const uint16_t*)X, partial, HW, C, gn_pix(HW));
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// per-channel affine (a, d) with y = x*a + d from chunk partials; called by every thread of a block
+__device__ __forceinline__ void gn_affine_to_lds(const float* __restrict__ partial, int nchunks, int b,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                                 int HW, float eps, float* sa, float* sd, float* smr) {
+  const int tid = threadIdx.x;
+  const int cpg = C >> 5;
+  if (tid < GN_G) {
+    double ss = 0.0, qq = 0.0;
+    const float* pp = partial + ((long long)b * nchunks * GN_G + tid) * 2;
+    for (int c = 0; c < nchunks; ++c) { ss += (double)pp[(long long)c * GN_G * 2]; qq += (double)pp[(long long)c * GN_G * 2 + 1]; }
+    const double n = (double)HW * (double)cpg;
+    const double mean = ss / n;
+    double var = qq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    smr[2 * tid] = (float)mean;
+    smr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float a = smr[2 * g + 1] * gamma[c];
+    sa[c] = a;
+    sd[c] = beta[c] - smr[2 * g] * a;
+  }
+  __syncthreads();
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix, int nchunks) {
+  __shared__ float sa[1024], sd[1024], ra[1024], rd[1024], smr[64];
+  const int b = blockIdx.y;
+  gn_affine_to_lds(p.partial, nchunks, b, p.gamma, p.beta, p.C, p.HW, p.eps, sa, sd, smr);
+  const bool r_gn = (p.R != nullptr) && (p.r_gamma != nullptr);
+  if (r_gn) gn_affine_to_lds(p.r_partial, nchunks, b, p.r_gamma, p.r_beta, p.C, p.HW, p.eps, ra, rd, smr);
+  const int cvec = p.C >> 3;
+  const int pbeg = blockIdx.x * pix;
+  const int pend = min(pbeg + pix, p.HW);
+  const long long img = (long long)b * p.HW * p.C;
+  const uint16_t* X = (const uint16_t*)p.X + img;
+  const uint16_t* R = p.R ? (const uint16_t*)p.R + img : nullptr;
+  uint16_t* Y = (uint16_t*)p.Y + img;
+  const int total = (pend - pbeg) * cvec;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int pi = i / cvec, v = i - pi * cvec;
+    const long long off = (long long)(pbeg + pi) * p.C + v * 8;
+    float f[8];
+    unpack8<DT>(*(const uint4*)(X + off), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = f[e] * sa[v * 8 + e] + sd[v * 8 + e];
+    if (R != nullptr) {
+      float r[8];
+      unpack8<DT>(*(const uint4*)(R + off), r);
+      if (r_gn) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = r[e] * ra[v * 8 + e] + rd[v * 8 + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += r[e];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+    }
+    *(uint4*)(Y + off) = pack8<DT>(f);
+  }
+}
+
+hipError_t launch_gn_apply(int dtype, const GnParams& p, hipStream_t stream) {
+  if (p.C % 64 != 0 || p.C > 1024) return hipErrorInvalidValue;
+  const int nch = gn_chunks(p.HW);
+  dim3 grid(nch, p.B);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<DT_BF16>, grid, dim3(256), 0, stream, p, gn_pix(p.HW), nch);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(gn_apply_kernel<DT_FP16>, grid, dim3(256), 0, stream, p, gn_pix(p.HW), nch);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// stem: GN + ReLU + MaxPool2dSame(3, stride 2): pad (0,1) bottom/right; padded taps are skipped
+// (equivalent to timm's -inf padding).  One thread = one output pixel x 8 channels.
+template <int DT>
+__global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ partial, int nchunks, int H, int W,
+                                                              int C, float eps) {
+  __shared__ float sa[1024], sd[1024], smr[64];
+  const int b = blockIdx.y;
+  gn_affine_to_lds(partial, nchunks, b, gamma, beta, C, H * W, eps, sa, sd, smr);
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int cvec = C >> 3;
+  const int total = Ho * Wo * cvec;
+  const uint16_t* Xi = X + (long long)b * H * W * C;
+  uint16_t* Yo = Y + (long long)b * Ho * Wo * C;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int v = i % cvec, po = i / cvec;
+    const int oy = po / Wo, ox = po - oy * Wo;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = 0.f;  // post-ReLU values are >= 0
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy + dy;
+      if (iy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = 2 * ox + dx;
+        if (ix >= W) continue;
+        float f[8];
+        unpack8<DT>(*(const uint4*)(Xi + ((long long)iy * W + ix) * C + v * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], f[e] * sa[v * 8 + e] + sd[v * 8 + e]);
+      }
+    }
+    *(uint4*)(Yo + (long long)po * C + v * 8) = pack8<DT>(m);
+  }
+}
+
+hipError_t launch_gn_relu_maxpool(int dtype, const void* X, void* Y, const float* gamma, const float* beta,
+                                  const float* partial, int B, int H, int W, int C, float eps, hipStream_t stream) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int total = Ho * Wo * (C / 8);
+  dim3 grid(min((total + 255) / 256, 1024), B);
+  const int nch = gn_chunks(H * W);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(gn_relu_maxpool_kernel<DT_BF16>, grid, dim3(256), 0, stream, (const uint16_t*)X, (uint16_t*)Y, gamma,
+                       beta, partial, nch, H, W, C, eps);
+  else if (dtype == DT_FP16)
+    hipLaunchKernelGGL(gn_relu_maxpool_kernel<DT_FP16>, grid, dim3(256), 0, stream, (const uint16_t*)X, (uint16_t*)Y, gamma,
+                       beta, partial, nch, H, W, C, eps);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace dptx

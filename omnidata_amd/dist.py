@@ -1,0 +1,51 @@
+"""Multi-GPU start-up for data-parallel inference.
+
+The path shards by image: every rank owns a full replica and independent batches, and the
+steady-state loop has NO collective.  The only exchange is at start-up: rank 0 folds / packs
+the weights once and the packed blob (~244 MB) is broadcast with torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of a global batch for `rank`; remainder goes to the low ranks."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_blob(blob: Optional[torch.Tensor], nbytes: int, device: torch.device, src: int = 0) -> torch.Tensor:
+    """Broadcasts a uint8 blob of known size from `src`; other ranks pass blob=None."""
+    if dist.get_rank() == src:
+        assert blob is not None and blob.numel() == nbytes and blob.dtype == torch.uint8
+        t = blob.to(device).contiguous()
+    else:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src)
+    return t
+
+
+def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dtype: str, device_index: int, src: int = 0):
+    """Every rank gets an Engine with identical packed weights; only `src` runs the host-side
+    fold/pack (state_dict_fn() is called on `src` only)."""
+    from .engine import Engine
+    eng = Engine(num_channels=num_channels, max_batch=max_batch, dtype=dtype, device_id=device_index)
+    device = torch.device("cuda", device_index)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        eng.load_state_dict(state_dict_fn())
+        return eng
+    if dist.get_rank() == src:
+        eng.load_state_dict(state_dict_fn())
+        blob = eng.export_packed()
+        torch.cuda.current_stream().synchronize()
+        broadcast_blob(blob, eng.packed_bytes, device, src)
+    else:
+        blob = broadcast_blob(None, eng.packed_bytes, device, src)
+        eng.import_packed(blob)
+    return eng

@@ -1,0 +1,181 @@
+"""ctypes binding of libdptx.so (include/dptx.h).  No CPU fallback: if the library or a GPU is
+missing the compute entry points raise -- the product never routes through oracle/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdptx.so")
+
+DTYPES = {"bf16": 0, "fp16": 1}
+ERRORS = {0: "ok", -1: "invalid argument / call order", -2: "state_dict key error", -3: "HIP error",
+          -4: "no device", -5: "allocation failed"}
+
+
+class DptxConfig(C.Structure):
+    _fields_ = [("num_channels", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32),
+                ("device_id", C.c_int32), ("non_negative", C.c_int32), ("ws_form", C.c_int32),
+                ("ws_eps", C.c_float), ("reserved", C.c_int32 * 8)]
+
+
+# (name, restype, argtypes) for every symbol declared in include/dptx.h
+_vp, _i32, _i64p, _f32p, _sz = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_size_t
+ABI = [
+    ("dptx_default_config", None, [C.POINTER(DptxConfig)]),
+    ("dptx_create", C.c_int, [C.POINTER(_vp), C.POINTER(DptxConfig)]),
+    ("dptx_destroy", None, [_vp]),
+    ("dptx_load_tensor", C.c_int, [_vp, C.c_char_p, _vp, _i64p, _i32]),
+    ("dptx_finalize_weights", C.c_int, [_vp]),
+    ("dptx_packed_bytes", _sz, [_vp]),
+    ("dptx_export_packed_host", C.c_int, [_vp, _vp, _sz]),
+    ("dptx_export_packed_device", C.c_int, [_vp, _vp, _sz, _vp]),
+    ("dptx_import_packed_device", C.c_int, [_vp, _vp, _sz, _vp]),
+    ("dptx_workspace_bytes", _sz, [_vp]),
+    ("dptx_forward", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    ("dptx_tap", C.c_int, [_vp, C.c_char_p, _vp, _sz, _i64p]),
+    ("dptx_enable_taps", C.c_int, [_vp, C.c_int]),
+    ("dptx_forward_info", C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("dptx_last_error", C.c_char_p, [_vp]),
+    ("dptx_version", C.c_char_p, []),
+    ("dptx_op_gemm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    ("dptx_op_conv", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [_vp]),
+    ("dptx_op_attention", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("dptx_op_layernorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
+    ("dptx_op_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp]),
+    ("dptx_op_upsample2x", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libdptx.so and declares every prototype.  Raises if the extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: run `python -m omnidata_amd.build` "
+                               "(or __graft_entry__.build()). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in ABI:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Engine:
+    """One dptx handle: packed weights + activation arena on one GPU (or host-only packing)."""
+
+    def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "bf16",
+                 device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8):
+        self.lib = load_library()
+        cfg = DptxConfig()
+        self.lib.dptx_default_config(C.byref(cfg))
+        cfg.num_channels, cfg.max_batch, cfg.dtype = num_channels, max_batch, DTYPES[dtype]
+        cfg.device_id = -1 if device_id is None else int(device_id)
+        cfg.non_negative, cfg.ws_form, cfg.ws_eps = int(non_negative), ws_form, ws_eps
+        self.cfg = cfg
+        self.dtype = dtype
+        self.h = _vp()
+        rc = self.lib.dptx_create(C.byref(self.h), C.byref(cfg))
+        if rc != 0:
+            self.h = None
+            raise RuntimeError(f"dptx_create failed: {ERRORS.get(rc, rc)}"
+                               + (" (no HIP device visible; the HIP path has no CPU fallback)" if rc == -4 else ""))
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.dptx_last_error(self.h).decode()
+            raise RuntimeError(f"{what} failed ({ERRORS.get(rc, rc)}): {msg}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dptx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        for k, v in sd.items():
+            a = v.detach().to("cpu", torch.float32).contiguous().numpy()
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.dptx_load_tensor(self.h, k.encode(), a.ctypes.data, shape, a.ndim), f"load_tensor({k})")
+        self._check(self.lib.dptx_finalize_weights(self.h), "finalize_weights")
+
+    @property
+    def packed_bytes(self) -> int:
+        return self.lib.dptx_packed_bytes(self.h)
+
+    @property
+    def workspace_bytes(self) -> int:
+        return self.lib.dptx_workspace_bytes(self.h)
+
+    def export_packed_host(self) -> np.ndarray:
+        buf = np.empty(self.packed_bytes, dtype=np.uint8)
+        self._check(self.lib.dptx_export_packed_host(self.h, buf.ctypes.data, buf.size), "export_packed_host")
+        return buf
+
+    def export_packed(self) -> torch.Tensor:
+        t = torch.empty(self.packed_bytes, dtype=torch.uint8, device=f"cuda:{self.cfg.device_id}")
+        self._check(self.lib.dptx_export_packed_device(self.h, t.data_ptr(), t.numel(), _stream()), "export_packed_device")
+        return t
+
+    def import_packed(self, blob: torch.Tensor):
+        assert blob.is_cuda and blob.dtype == torch.uint8 and blob.is_contiguous()
+        self._check(self.lib.dptx_import_packed_device(self.h, blob.data_ptr(), blob.numel(), _stream()), "import_packed_device")
+        torch.cuda.current_stream().synchronize()
+
+    # ---- compute
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("dptx forward needs a CUDA(HIP) tensor; there is no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != 384 or x.shape[3] != 384:
+            raise ValueError(f"expected [B,3,384,384], got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        if out is None:
+            out = torch.empty(B, self.cfg.num_channels, 384, 384, dtype=torch.float32, device=x.device)
+        self._check(self.lib.dptx_forward(self.h, x.data_ptr(), 0, out.data_ptr(), B, _stream()), "forward")
+        return out
+
+    def enable_taps(self, on: bool = True):
+        self._check(self.lib.dptx_enable_taps(self.h, int(on)), "enable_taps")
+
+    def tap(self, name: str) -> torch.Tensor:
+        """Stage activation of the last forward as an fp32 CPU tensor in NCHW ([B,577,768] for tokens)."""
+        shape = (C.c_int64 * 4)()
+        probe = np.empty(1, dtype=np.float32)
+        rc = self.lib.dptx_tap(self.h, name.encode(), probe.ctypes.data, 0, shape)  # size query
+        if rc == -2:
+            self._check(rc, f"tap({name})")
+        b, h, w, c = list(shape)
+        buf = np.empty(b * h * w * c, dtype=np.float32)
+        self._check(self.lib.dptx_tap(self.h, name.encode(), buf.ctypes.data, buf.size, shape), f"tap({name})")
+        t = torch.from_numpy(buf).reshape(b, h, w, c)
+        if name.startswith(("tok", "blk")):
+            return t.reshape(b, h, w)
+        return t.permute(0, 3, 1, 2).contiguous()
+
+    def info(self) -> Tuple[int, float, float]:
+        n, a, e = C.c_int64(), C.c_double(), C.c_double()
+        self._check(self.lib.dptx_forward_info(self.h, C.byref(n), C.byref(a), C.byref(e)), "forward_info")
+        return n.value, a.value, e.value

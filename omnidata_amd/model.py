@@ -1,0 +1,132 @@
+"""Host-side mirror of the reference's model class for the one supported path.
+
+``DPTDepthModel`` keeps the constructor, ``state_dict`` key names, ``load_state_dict`` /
+``.to()`` / ``.eval()`` behaviour and the forward contract of
+``omnidata_tools/torch/modules/midas/dpt_depth.py:87-107`` (DPT.forward :67-85), but the
+forward pass runs in libdptx.so (hand-written gfx950 kernels) instead of ATen.
+PyTorch is only plumbing here: parameter storage, device memory, streams.
+
+There is deliberately NO CPU / eager fallback: calling the model with CPU tensors, without a
+GPU, or without the built extension raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+from .weights import random_state_dict, read_checkpoint, state_dict_spec
+
+
+class _Node(nn.Module):
+    """Anonymous container so that nested parameter names equal the reference's keys."""
+
+
+class BaseModel(nn.Module):
+    def load(self, path: str):
+        """Same contract as modules/midas/base_model.py:4-16 (plus Lightning .ckpt dicts)."""
+        self.load_state_dict(read_checkpoint(path))
+
+
+class DPTDepthModel(BaseModel):
+    """Drop-in for ``DPTDepthModel(backbone='vitb_rn50_384', num_channels={1,3})``.
+
+    Extra keyword arguments (engine side): ``dtype`` in {'bf16','fp16'} -- MFMA operand /
+    activation storage type; ``max_batch`` -- arena size (larger batches are chunked).
+    """
+
+    def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,
+                 backbone: str = "vitb_rn50_384", features: int = 256, readout: str = "project",
+                 channels_last: bool = False, use_bn: bool = False, dtype: str = "bf16",
+                 max_batch: int = 32, init_seed: int = 0):
+        super().__init__()
+        if backbone != "vitb_rn50_384":
+            # blocks.py:42-44: unknown backbones print and assert
+            print(f"Backbone '{backbone}' not implemented")
+            assert False, "only the DPT-Hybrid backbone 'vitb_rn50_384' is built for MI355X"
+        if features != 256 or readout != "project" or use_bn:
+            raise NotImplementedError("only features=256, readout='project', use_bn=False (the published "
+                                      "omnidata DPT-Hybrid configuration) is supported")
+        if num_channels not in (1, 3):
+            raise ValueError("num_channels must be 1 (depth) or 3 (surface normals)")
+        self.num_channels = num_channels
+        self.non_negative = bool(non_negative)
+        self.channels_last = channels_last  # accepted and, as in the reference (dpt_depth.py:68-69), a no-op
+        self.engine_dtype = dtype
+        self.max_batch = int(max_batch)
+        init = random_state_dict(init_seed, num_channels)
+        for key, shape in state_dict_spec(num_channels).items():
+            *mods, leaf = key.split(".")
+            node = self
+            for m in mods:
+                if not hasattr(node, m):
+                    node.add_module(m, _Node())
+                node = getattr(node, m)
+            node.register_parameter(leaf, nn.Parameter(init[key], requires_grad=False))
+        self._engine: Optional[Engine] = None
+        self._engine_key = None
+        self._weights_version = 0
+        if path is not None:
+            self.load(path)
+
+    # ---- keep the engine in sync with the parameters
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._weights_version += 1
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._weights_version += 1
+        return r
+
+    def _get_engine(self, device: torch.device) -> Engine:
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               self._weights_version, self.engine_dtype, self.max_batch)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            eng = Engine(num_channels=self.num_channels, max_batch=self.max_batch, dtype=self.engine_dtype,
+                         device_id=key[0], non_negative=self.non_negative)
+            eng.load_state_dict(super().state_dict())
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
+    @property
+    def engine(self) -> Optional[Engine]:
+        return self._engine
+
+    def adopt_engine(self, engine: Engine, device_index: int):
+        """Use an engine whose packed weights arrived by broadcast (multi-GPU start-up)."""
+        self._engine = engine
+        self._engine_key = (device_index, self._weights_version, self.engine_dtype, self.max_batch)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("omnidata_amd.DPTDepthModel runs only on an AMD GPU (HIP); got a CPU tensor. "
+                               "There is no CPU fallback -- use the reference implementation on CPU.")
+        eng = self._get_engine(x.device)
+        B = x.shape[0]
+        if B <= self.max_batch:
+            y = eng.forward(x)
+        else:
+            y = torch.empty(B, self.num_channels, 384, 384, dtype=torch.float32, device=x.device)
+            for i in range(0, B, self.max_batch):
+                eng.forward(x[i:i + self.max_batch], out=y[i:i + self.max_batch])
+        return y.squeeze(dim=1)  # dpt_depth.py:106-107
+
+
+def build_model(task: str = "normal", weights: Optional[str] = None, random_weights: Optional[int] = None,
+                **kw) -> DPTDepthModel:
+    """normal -> 3 channels, depth -> 1 channel (demo.py:63,82)."""
+    if task not in ("normal", "depth"):
+        raise ValueError("task should be one of the following: normal, depth")
+    C = 3 if task == "normal" else 1
+    model = DPTDepthModel(backbone="vitb_rn50_384", num_channels=C,
+                          init_seed=0 if random_weights is None else random_weights, **kw)
+    if weights is not None:
+        model.load_state_dict(read_checkpoint(weights))
+    return model.eval()

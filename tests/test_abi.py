@@ -1,0 +1,147 @@
+"""C-ABI library: loads, exports every symbol include/dptx.h declares, and the host-side
+weight folding / packing (no GPU needed: host-only handles, device_id = -1)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from omnidata_amd.weights import random_state_dict, state_dict_spec, is_unused
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dptx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dptx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/dptx.h but not exported"
+
+
+def test_python_binding_covers_header(built_lib):
+    from omnidata_amd.engine import ABI, load_library
+    load_library()
+    assert sorted(n for n, _, _ in ABI) == declared_symbols()
+
+
+def test_device_handle_fails_loudly_without_gpu(built_lib):
+    from omnidata_amd.engine import Engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no device"):
+        Engine(device_id=0)
+
+
+def test_strict_loading_errors(built_lib):
+    from omnidata_amd.engine import Engine
+    e = Engine(num_channels=3, max_batch=1, device_id=None)
+    sd = random_state_dict(0, 3)
+    with pytest.raises(RuntimeError, match="unexpected key"):
+        e.load_state_dict({"not.a.key": torch.zeros(1)})
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        e.load_state_dict({"scratch.output_conv.4.bias": torch.zeros(1)})  # C=3 expects [3]
+    partial = {k: v for k, v in sd.items() if "blocks.7.attn.qkv" not in k}
+    with pytest.raises(RuntimeError, match="missing tensors.*blocks.7.attn.qkv.weight"):
+        e.load_state_dict(partial)
+    # the tensors the forward never reads may be absent (and are ignored when present)
+    e2 = Engine(num_channels=3, max_batch=1, device_id=None)
+    e2.load_state_dict({k: v for k, v in sd.items() if not is_unused(k)})
+    e3 = Engine(num_channels=3, max_batch=1, device_id=None)
+    e3.load_state_dict(sd)
+    assert np.array_equal(e2.export_packed_host(), e3.export_packed_host())
+    with pytest.raises(RuntimeError, match="host-only"):
+        e3._check(e3.lib.dptx_forward(e3.h, 1, 0, 1, 1, None), "forward")
+
+
+def _blob_offsets(spec_items, dtype_bytes=2):
+    """Re-derives the packed layout: entries in spec order, 256-B aligned."""
+    off, out = 0, {}
+    for k, shape in spec_items:
+        if is_unused(k):
+            continue
+        n = int(np.prod(shape))
+        if k.endswith("stem.conv.weight"):
+            b = 64 * 192 * 2
+        elif k == "scratch.output_conv.4.weight":
+            b = n * 4
+        elif k.endswith(".weight") and len(shape) >= 2:
+            b = n * 2
+        else:
+            b = n * 4
+        out[k] = (off, b)
+        off += (b + 255) // 256 * 256
+    return out, off
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_packed_weights_match_numpy_fold(built_lib, dtype):
+    from omnidata_amd.engine import Engine
+    from oracle.dpt_oracle import standardize_weight
+    C = 1
+    sd = random_state_dict(3, C)
+    e = Engine(num_channels=C, max_batch=2, dtype=dtype, device_id=None)
+    e.load_state_dict(sd)
+    blob = e.export_packed_host()
+    offs, total = _blob_offsets(state_dict_spec(C).items())
+    assert total == blob.size == e.packed_bytes
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+
+    def packed16(key, n):
+        o, b = offs[key]
+        return torch.from_numpy(blob[o:o + 2 * n].copy()).view(tdt).float()
+
+    # linear: plain RNE conversion
+    k = "pretrained.model.blocks.5.mlp.fc1.weight"
+    assert torch.equal(packed16(k, sd[k].numel()), sd[k].to(tdt).float().flatten())
+    # plain conv: OIHW -> O,kh,kw,I
+    k = "scratch.refinenet2.resConfUnit1.conv2.weight"
+    assert torch.equal(packed16(k, sd[k].numel()), sd[k].permute(0, 2, 3, 1).to(tdt).float().flatten())
+    # StdConv (3x3 and 1x1): standardised (timm 0.4.x form, eps 1e-8), then re-laid out
+    for k in ("pretrained.model.patch_embed.backbone.stages.1.blocks.0.conv2.weight",
+              "pretrained.model.patch_embed.backbone.stages.2.blocks.3.conv3.weight"):
+        ref = standardize_weight(sd[k].double(), 1e-8, "timm04").permute(0, 2, 3, 1).flatten()
+        got = packed16(k, sd[k].numel()).double()
+        tol = 2.0 ** (-8 if dtype == "bf16" else -11) * ref.abs().clamp_min(1e-3)  # <= 1 ulp: fold done in double
+        assert bool(((got - ref).abs() <= tol).all())
+        assert (got - ref.float().to(tdt).double()).abs().max() <= 2.0 ** (-7 if dtype == "bf16" else -10) * ref.abs().max()
+    # stem: [64][192], k = (ky*7+kx)*3 + c, zero padded from 147
+    k = "pretrained.model.patch_embed.backbone.stem.conv.weight"
+    got = packed16(k, 64 * 192).reshape(64, 192)
+    ref = standardize_weight(sd[k].double(), 1e-8, "timm04").permute(0, 2, 3, 1).reshape(64, 147)
+    assert torch.all(got[:, 147:] == 0)
+    assert (got[:, :147].double() - ref).abs().max() <= 2.0 ** (-7 if dtype == "bf16" else -10) * ref.abs().max()
+    # fp32 vectors verbatim
+    for k in ("pretrained.model.pos_embed", "scratch.output_conv.4.weight", "pretrained.model.blocks.0.norm1.bias"):
+        o, b = offs[k]
+        assert torch.equal(torch.from_numpy(blob[o:o + b].copy()).view(torch.float32), sd[k].flatten())
+
+
+def test_fp16_conversion_edge_cases(built_lib):
+    """Host fp32->fp16 RNE (engine.hip f32_to_fp16) against torch, incl. subnormals/overflow."""
+    from omnidata_amd.engine import Engine
+    vals = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e6, 6.1035e-5, 6.0e-5, 5.96e-8, 2.98e-8,
+                         2.9e-8, 1e-9, 0.333333, 1.0009765625, 1.00048828125, 1.00146484375, -3.14159, 12345.678])
+    sd = random_state_dict(0, 3)
+    k = "pretrained.model.blocks.0.attn.proj.weight"
+    w = sd[k].clone()
+    w.view(-1)[: vals.numel()] = vals
+    rnd = torch.randn(4096) * torch.logspace(-9, 5, 4096)
+    w.view(-1)[100:100 + 4096] = rnd
+    sd[k] = w
+    e = Engine(num_channels=3, max_batch=1, dtype="fp16", device_id=None)
+    e.load_state_dict(sd)
+    blob = e.export_packed_host()
+    offs, _ = _blob_offsets(state_dict_spec(3).items())
+    o, b = offs[k]
+    got = torch.from_numpy(blob[o:o + b].copy()).view(torch.float16)
+    ref = w.flatten().to(torch.float16)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))

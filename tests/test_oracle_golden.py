@@ -1,0 +1,43 @@
+"""The CPU oracle against the golden vectors produced by the REFERENCE's own modules
+(oracle/validate_vs_reference.py, run where /root/reference exists).  No GPU."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from omnidata_amd.weights import random_state_dict, synthetic_input
+from oracle.dpt_oracle import dpt_forward, ssi_align, mean_angular_error_deg
+from oracle.validate_vs_reference import GOLDEN_TAPS, stats, subsample
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dpt_*.npz")))
+
+
+def test_golden_files_present():
+    assert len(GOLDEN) >= 4
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_matches_reference_golden(path):
+    g = np.load(path)
+    task, C, seed, B = str(g["task"]), int(g["num_channels"]), int(g["seed"]), int(g["batch"])
+    torch.set_num_threads(os.cpu_count())
+    taps = {}
+    y = dpt_forward(random_state_dict(seed, C), synthetic_input(seed, B, task), taps)
+    assert tuple(y.shape) == ((B, 3, 384, 384) if C == 3 else (B, 384, 384))
+    # fp32 oracle vs fp32 reference: same ops, so only thread-count reassociation noise
+    np.testing.assert_allclose(subsample(y), g["out_sub"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(y.reshape(B, -1, 384, 384)[0, 0, 191].numpy(), g["out_row"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(stats(y)[:3], g["out_stats"][:3], rtol=1e-4, atol=1e-5)
+    for name in GOLDEN_TAPS:
+        ref = g["tap_" + name]
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(subsample(taps[name]), ref, atol=3e-5 * scale, rtol=0, err_msg=name)
+
+
+def test_metrics_helpers():
+    a = torch.rand(2, 16, 16)
+    assert torch.allclose(ssi_align(3 * a + 0.5, a), a, atol=1e-5)
+    n = torch.rand(1, 3, 8, 8)
+    assert mean_angular_error_deg(n, n) < 0.05
