@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- DPT-Hybrid-384 surface-normal inference throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one forward of the hot path (dptx_forward through the C ABI) over one batch of 32
+synthetic 384x384 images that are already resident in HBM (BASELINE.json configs[1]: DPT-Hybrid-384
+surface normals, batch 32, bf16, one MI355X).  With N > 1 every rank owns a replica (weights
+packed once on rank 0 and broadcast over RCCL/xGMI) and its own batch; there is no collective in
+the timed loop (weak scaling).  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     : MFMA roofline of the dominant kernel family (the implicit-GEMM MFMA kernel that
+                 runs every conv / linear).  achieved = algorithmic FLOPs routed through it per
+                 forward / its summed launch durations, measured with HIP events on the forward's
+                 stream in profiled forwards run right after the timed region.
+  cpu_baseline : the CPU fp32 oracle (oracle/dpt_oracle.py, a port of the reference forward) timed
+                 on this host's cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE = {"normal": 255.25, "depth": 255.23}          # SURVEY.md 8d (algorithmic)
+GEMM_GMAC_PER_IMAGE = {"normal": 121.487, "depth": 121.478}    # A.6: convs + linears (attention excluded)
+PEAK_TFLOPS = 2500.0                                           # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--task", default="normal", choices=["normal", "depth"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path exists only as HIP kernels (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from omnidata_amd.build import build
+    if rank == 0 or not os.path.exists(os.path.join(ROOT, "omnidata_amd", "libdptx.so")):
+        build()
+    if world > 1:
+        dist.barrier()
+    from omnidata_amd.dist import build_replicated_engine
+    from omnidata_amd.weights import random_state_dict, synthetic_input
+
+    C = 3 if args.task == "normal" else 1
+    eng = build_replicated_engine(lambda: random_state_dict(0, C), C, args.batch, args.dtype, local_rank)
+    x = synthetic_input(1000 + rank, args.batch, args.task).to(device)
+    y = torch.empty(args.batch, C, 384, 384, dtype=torch.float32, device=device)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.forward(x, out=y)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward(x, out=y)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(y).all()
+
+    # ---- roofline of the dominant kernel family: HIP events around every launch, separate passes
+    roofline = None
+    breakdown = None
+    if rank == 0:
+        eng.set_profiling(True)
+        acc = {}
+        for _ in range(max(1, args.profile_steps)):
+            eng.forward(x, out=y)
+            torch.cuda.synchronize()
+            for k, (ms, n, macs) in eng.profile().items():
+                a = acc.setdefault(k, [0.0, n, macs])
+                a[0] += ms
+        eng.set_profiling(False)
+        P = max(1, args.profile_steps)
+        breakdown = {k: {"ms_per_step": round(v[0] / P, 4), "launches": v[1], "executed_gmac_per_image": round(v[2] / 1e9, 3)}
+                     for k, v in acc.items()}
+        gemm_ms = acc["gemm"][0] / P
+        gemm_flop = 2.0 * GEMM_GMAC_PER_IMAGE[args.task] * 1e9 * args.batch
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "dptx::gemm_kernel (implicit-GEMM MFMA, all conv/linear launches)",
+                    "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": acc["gemm"][1], "avg_launch_ms": round(gemm_ms / max(1, acc["gemm"][1]), 5),
+                    "algorithmic_gflop_per_step": round(gemm_flop / 1e9, 1),
+                    "executed_gflop_per_step": round(2 * acc["gemm"][2] * args.batch / 1e9, 1)}
+
+    # ---- CPU baseline: the fp32 oracle on this host, bounded sample
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.dpt_oracle import dpt_forward
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        sd = random_state_dict(0, C)
+        xc = synthetic_input(1000, 4, args.task)
+        dpt_forward(sd, xc[:1])  # warm-up
+        t1 = time.perf_counter()
+        n_img = 0
+        while True:
+            dpt_forward(sd, xc)
+            n_img += xc.shape[0]
+            if time.perf_counter() - t1 > 12.0 or n_img >= 64:
+                break
+        dt_cpu = time.perf_counter() - t1
+        cpu_baseline = {"value": round(n_img / dt_cpu, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+                        "kind": "port", "sample": f"{n_img} images (batches of 4) of the same synthetic 384x384 workload, fp32"}
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        value = total_images / elapsed
+        e2e_tflops = value * GFLOP_PER_IMAGE[args.task] / 1e3
+        line = {
+            "metric": "images/sec (384x384) DPT-Hybrid surface-normal inference" if args.task == "normal"
+                      else "images/sec (384x384) DPT-Hybrid depth inference",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic 384x384 inputs resident in HBM; seeded random weights",
+            "config": {"workload": f"DPT-Hybrid-384 {args.task}, batch {args.batch}/GPU, {args.dtype}, {world}xMI355X "
+                                   "(BASELINE.json configs[1])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"replicas x{world} (no collective in the loop)"},
+            "e2e_mfma_frac": round(e2e_tflops / (PEAK_TFLOPS * world), 4),
+            "e2e_tflops_algorithmic": round(e2e_tflops, 1),
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernel_breakdown": breakdown,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

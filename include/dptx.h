@@ -118,6 +118,14 @@ int dptx_enable_taps(dptx_handle h, int on);
 int dptx_forward_info(dptx_handle h, int64_t* launches, double* algorithmic_macs,
                       double* executed_macs);
 
+/* Per-launch timing of the NEXT forwards with one HIP event after every launch on the forward's
+ * stream (kernels of one forward are serialized, so consecutive events bracket one kernel plus
+ * its launch gap).  dptx_profile_get sums the last forward by category:
+ * 0 = implicit-GEMM MFMA kernel, 1 = attention, 2 = LayerNorm/GroupNorm, 3 = other glue. */
+int dptx_set_profiling(dptx_handle h, int on);
+int dptx_profile_get(dptx_handle h, int32_t category, double* ms, int64_t* launches,
+                     double* macs_per_image);
+
 const char* dptx_last_error(dptx_handle h);
 const char* dptx_version(void);
 

@@ -222,6 +222,13 @@ struct dptx_engine {
   int64_t launches = 0;
   double exec_macs = 0.0;
   int last_batch = 0;
+  // optional per-launch timing (one event after every launch; kernels are serialized on the stream)
+  bool profiling = false;
+  std::vector<hipEvent_t> events;
+  std::vector<int> event_cat;
+  double cat_ms[4] = {0, 0, 0, 0};
+  int64_t cat_launches[4] = {0, 0, 0, 0};
+  double cat_macs[4] = {0, 0, 0, 0};
 
   // arena slices
   Buf col, sraw, stem, S[3], T1, T2, PA, PB, DS, part[4], X, Hn, QKV, AO, F1, R3, R4, L3, T4, L4, clsb, lrn[4], tA, tB,
@@ -349,9 +356,19 @@ struct Run {
   hipError_t err = hipSuccess;
   const char* where = "";
 
-  void chk(hipError_t r, const char* w) {
+  void chk(hipError_t r, const char* w, int cat = 3) {
     if (err == hipSuccess && r != hipSuccess) { err = r; where = w; }
     e->launches++;
+    if (e->profiling) {
+      const size_t i = e->event_cat.size() + 1;  // events[0] marks the start of the forward
+      if (i >= e->events.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        e->events.push_back(ev);
+      }
+      (void)hipEventRecord(e->events[i], st);
+      e->event_cat.push_back(cat);
+    }
   }
   void tap(const char* name, const void* p, int64_t h, int64_t w, int64_t c, bool fp32 = false) {
     e->taps[name] = TapInfo{p, {B, h, w, c}, fp32};
@@ -370,10 +387,11 @@ struct Run {
     p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = Cout;
     p.act = act; p.a_relu = a_relu;
     e->exec_macs += (double)p.M / B * p.N * p.K;
-    chk(launch_gemm(dt, p, st), wkey.c_str());
+    e->cat_macs[0] += (double)p.M / B * p.N * p.K;
+    chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
   }
 
-  void gn_stats(const void* X, float* part, int HW, int C) { chk(launch_gn_stats(dt, X, part, B, HW, C, st), "gn_stats"); }
+  void gn_stats(const void* X, float* part, int HW, int C) { chk(launch_gn_stats(dt, X, part, B, HW, C, st), "gn_stats", 2); }
   void gn_apply(void* X, const std::string& nkey, float* part, int HW, int C, int relu, const void* R = nullptr,
                 const std::string& rkey = "", const float* rpart = nullptr) {
     GnParams g{};
@@ -381,7 +399,7 @@ struct Run {
     g.R = R;
     if (!rkey.empty()) { g.r_gamma = e->f(rkey + ".weight"); g.r_beta = e->f(rkey + ".bias"); g.r_partial = rpart; }
     g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = 1e-5f;
-    chk(launch_gn_apply(dt, g, st), nkey.c_str());
+    chk(launch_gn_apply(dt, g, st), nkey.c_str(), 2);
   }
 
   // RCU (blocks.py:263-286): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
@@ -398,6 +416,15 @@ int Run::forward(const float* x, float* y) {
   E->taps.clear();
   E->launches = 0;
   E->exec_macs = 0.0;
+  for (int c = 0; c < 4; ++c) E->cat_macs[c] = 0.0;
+  E->event_cat.clear();
+  if (E->profiling) {
+    if (E->events.empty()) {
+      hipEvent_t ev;
+      if (hipEventCreate(&ev) == hipSuccess) E->events.push_back(ev);
+    }
+    if (!E->events.empty()) (void)hipEventRecord(E->events[0], st);
+  }
   const std::string vp = "pretrained.model.";
   const std::string bp = vp + "patch_embed.backbone.";
   float* part0 = (float*)E->a(E->part[0]);
@@ -412,12 +439,13 @@ int Run::forward(const float* x, float* y) {
     gemm_params_dense(p, B * 36864, 64, STEM_K);
     p.A = E->a(E->col); p.W = E->w(bp + "stem.conv.weight"); p.C = E->a(E->sraw);
     E->exec_macs += 36864.0 * 64 * STEM_K;
-    chk(launch_gemm(dt, p, st), "stem.conv");
+    E->cat_macs[0] += 36864.0 * 64 * STEM_K;
+    chk(launch_gemm(dt, p, st), "stem.conv", 0);
   }
   gn_stats(E->a(E->sraw), part0, 36864, 64);
   chk(launch_gn_relu_maxpool(dt, E->a(E->sraw), E->a(E->stem), E->f(bp + "stem.norm.weight"), E->f(bp + "stem.norm.bias"),
                              part0, B, 192, 192, 64, 1e-5f, st),
-      "stem.pool");
+      "stem.pool", 2);
   tap("stem", E->a(E->stem), 96, 96, 64);
 
   // ---- ResNetV2 stages (3,4,9) non-preact bottlenecks -----------------------------------
@@ -466,7 +494,8 @@ int Run::forward(const float* x, float* y) {
     p.c_rpi = 576; p.c_img_rows = S_TOK; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
     p.R2 = E->f(vp + "pos_embed"); p.r2_bcast = 1; p.r2_fp32 = 1;
     E->exec_macs += 576.0 * D_VIT * 1024;
-    chk(launch_gemm(dt, p, st), "patch_embed.proj");
+    E->cat_macs[0] += 576.0 * D_VIT * 1024;
+    chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
   }
   chk(launch_cls_rows(E->f(vp + "cls_token"), E->f(vp + "pos_embed"), X, B, S_TOK, D_VIT, st), "cls_rows");
   const int M = B * S_TOK;
@@ -486,7 +515,8 @@ int Run::forward(const float* x, float* y) {
     p.A = A; p.a_fp32 = a_fp32; p.W = E->w(wkey); p.C = C; p.c_fp32 = c_fp32; p.bias = bias; p.act = act;
     p.R1 = R1; p.r1_fp32 = r1_fp32;
     E->exec_macs += (double)S_TOK * N * K;
-    chk(launch_gemm(dt, p, st), wkey.c_str());
+    E->cat_macs[0] += (double)S_TOK * N * K;
+    chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
   };
 
   // ProjectReadout + reassemble for hook n (3 -> block 8, 4 -> block 11)
@@ -507,7 +537,8 @@ int Run::forward(const float* x, float* y) {
     p.c_rpi = 576; p.c_img_rows = 576; p.c_row_off = 0; p.ldc = D_VIT;
     p.bias = clsb; p.bias_per_img = 1; p.act = 2;
     E->exec_macs += 576.0 * D_VIT * D_VIT;
-    chk(launch_gemm(dt, p, st), "readout");
+    E->cat_macs[0] += 576.0 * D_VIT * D_VIT;
+    chk(launch_gemm(dt, p, st), "readout", 0);
     if (n == 3) {
       conv(R, 24, 24, D_VIT, pp + "3.weight", 1, 1, 0, 0, 24, 24, D_VIT, E->a(E->L3), E->f(pp + "3.bias"), 0, 0);
       tap("l3", E->a(E->L3), 24, 24, D_VIT);
@@ -521,12 +552,13 @@ int Run::forward(const float* x, float* y) {
   // ---- 12 transformer blocks (timm Block; LN eps 1e-6) -----------------------------------
   for (int l = 0; l < 12; ++l) {
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
-    chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, st), "ln1");
+    chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, st), "ln1", 2);
     dense(E->a(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, E->a(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0);
-    chk(launch_attention(dt, E->a(E->QKV), E->a(E->AO), B, S_TOK, N_HEADS, st), "attention");
+    chk(launch_attention(dt, E->a(E->QKV), E->a(E->AO), B, S_TOK, N_HEADS, st), "attention", 1);
     E->exec_macs += 2.0 * N_HEADS * (double)S_TOK * S_TOK * 64;
+    E->cat_macs[1] += 2.0 * N_HEADS * (double)S_TOK * S_TOK * 64;
     dense(E->a(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1);
-    chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, st), "ln2");
+    chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, st), "ln2", 2);
     dense(E->a(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, E->a(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0);
     dense(E->a(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1);
     {
@@ -646,6 +678,7 @@ void dptx_destroy(dptx_handle h) {
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
+    for (auto ev : h->events) (void)hipEventDestroy(ev);
   }
   delete h;
 }
@@ -770,6 +803,33 @@ int dptx_forward_info(dptx_handle h, int64_t* launches, double* algorithmic_macs
   if (launches) *launches = h->launches;
   if (algorithmic_macs) *algorithmic_macs = h->cfg.num_channels == 3 ? 127.624e9 : 127.615e9;
   if (executed_macs) *executed_macs = h->exec_macs;
+  return DPTX_OK;
+}
+
+int dptx_set_profiling(dptx_handle h, int on) {
+  if (!h) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
+  h->profiling = on != 0;
+  return DPTX_OK;
+}
+
+int dptx_profile_get(dptx_handle h, int32_t category, double* ms, int64_t* launches, double* macs_per_image) {
+  if (!h || category < 0 || category > 3) return DPTX_E_INVALID;
+  if (h->event_cat.empty()) return h->fail(DPTX_E_INVALID, "no profiled forward recorded");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipEventSynchronize(h->events[h->event_cat.size()]));
+  double t = 0.0;
+  int64_t n = 0;
+  for (size_t i = 0; i < h->event_cat.size(); ++i) {
+    if (h->event_cat[i] != category) continue;
+    float dt = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&dt, h->events[i], h->events[i + 1]));
+    t += dt;
+    ++n;
+  }
+  if (ms) *ms = t;
+  if (launches) *launches = n;
+  if (macs_per_image) *macs_per_image = h->cat_macs[category];
   return DPTX_OK;
 }
 

@@ -40,6 +40,8 @@ ABI = [
     ("dptx_tap", C.c_int, [_vp, C.c_char_p, _vp, _sz, _i64p]),
     ("dptx_enable_taps", C.c_int, [_vp, C.c_int]),
     ("dptx_forward_info", C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("dptx_set_profiling", C.c_int, [_vp, C.c_int]),
+    ("dptx_profile_get", C.c_int, [_vp, _i32, C.POINTER(C.c_double), _i64p, C.POINTER(C.c_double)]),
     ("dptx_last_error", C.c_char_p, [_vp]),
     ("dptx_version", C.c_char_p, []),
     ("dptx_op_gemm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -174,6 +176,18 @@ class Engine:
         if name.startswith(("tok", "blk")):
             return t.reshape(b, h, w)
         return t.permute(0, 3, 1, 2).contiguous()
+
+    def set_profiling(self, on: bool = True):
+        self._check(self.lib.dptx_set_profiling(self.h, int(on)), "set_profiling")
+
+    def profile(self) -> Dict[str, Tuple[float, int, float]]:
+        """{category: (ms, launches, executed MACs per image)} of the last profiled forward."""
+        out = {}
+        for i, name in enumerate(("gemm", "attention", "norm", "other")):
+            ms, n, macs = C.c_double(), C.c_int64(), C.c_double()
+            self._check(self.lib.dptx_profile_get(self.h, i, C.byref(ms), C.byref(n), C.byref(macs)), "profile_get")
+            out[name] = (ms.value, n.value, macs.value)
+        return out
 
     def info(self) -> Tuple[int, float, float]:
         n, a, e = C.c_int64(), C.c_double(), C.c_double()

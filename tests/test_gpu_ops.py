@@ -1,0 +1,151 @@
+"""Op-level parity of every HIP kernel against a plain PyTorch fp32 reference of the same op on
+the same (already 16-bit-rounded) inputs.  Run on an MI355X: pytest -m gpu."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from omnidata_amd.engine import DTYPES, load_library
+from tests.gpu_util import OUT_TOL, TDT, op_conv, op_gemm, ptr, rel_err, stream
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, dtype="bf16", scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(TDT[dtype]).to(DEV)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 256, 192), (577 * 3, 768, 768), (18464, 2304, 768),
+                                   (4608, 256, 2304), (300, 64, 576), (70000, 64, 64), (5000, 32, 1152), (77, 3072, 768)])
+def test_gemm_plain(dtype, M, N, K):
+    # asymmetric, non-identity operands: a row/col swap or a k-permutation mismatch cannot pass
+    A, W = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    ref = A.float() @ W.float().t()
+    got = op_gemm(dtype, A, W)
+    assert rel_err(got.float(), ref) < OUT_TOL[dtype]
+    got32 = op_gemm(dtype, A, W, c_fp32=True)
+    assert rel_err(got32, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_gemm_epilogues(dtype):
+    M, N, K = 1731, 768, 768
+    A, W = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=4)
+    bias = torch.randn(N, device=DEV)
+    R16 = rnd(M, N, dtype=dtype, seed=5)
+    R32 = torch.randn(M, N, device=DEV)
+    base = A.float() @ W.float().t() + bias
+    assert rel_err(op_gemm(dtype, A, W, bias, act=1).float(), F.relu(base)) < OUT_TOL[dtype]
+    assert rel_err(op_gemm(dtype, A, W, bias, act=2).float(), F.gelu(base)) < OUT_TOL[dtype]
+    assert rel_err(op_gemm(dtype, A, W, bias, R=R16).float(), base + R16.float()) < OUT_TOL[dtype]
+    assert rel_err(op_gemm(dtype, A, W, bias, R=R32, c_fp32=True), base + R32) < 2e-5
+    # fp32 A operand (ProjectReadout reads the fp32 token stream): rounded to 16-bit while staging
+    A32 = torch.randn(M, K, device=DEV)
+    ref = A32.to(TDT[dtype]).float() @ W.float().t() + bias
+    assert rel_err(op_gemm(dtype, A32, W, bias, c_fp32=True), ref) < 2e-5
+
+
+def conv_ref(X, Wt, bias, stride, pad_t, pad_l, Ho, Wo, a_relu):
+    x = X.float().permute(0, 3, 1, 2)
+    if a_relu:
+        x = F.relu(x)
+    k = Wt.shape[1]
+    H, W = x.shape[-2:]
+    pb = max((Ho - 1) * stride + k - H - pad_t, 0)
+    pr = max((Wo - 1) * stride + k - W - pad_l, 0)
+    x = F.pad(x, [pad_l, pr, pad_t, pb])
+    y = F.conv2d(x, Wt.float().permute(0, 3, 1, 2), bias, stride)
+    assert y.shape[-2:] == (Ho, Wo)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [
+    # B, H, Cin, Cout, k, stride, pad_t, Ho, a_relu, act, residual
+    (2, 24, 256, 256, 3, 1, 1, 24, 1, 1, False),   # RCU conv1: pre-ReLU + ReLU epilogue
+    (2, 24, 256, 256, 3, 1, 1, 24, 0, 0, True),    # RCU conv2: + residual
+    (3, 48, 128, 128, 3, 2, 0, 24, 0, 0, False),   # bottleneck conv2 stride 2, TF-SAME pad (0,1)
+    (2, 48, 256, 512, 1, 2, 0, 24, 0, 0, False),   # downsample 1x1 stride 2
+    (1, 24, 768, 768, 3, 2, 1, 12, 0, 0, False),   # act_postprocess4 conv 3x3 s2 p1
+    (2, 96, 64, 64, 3, 1, 1, 96, 0, 0, False),     # stage0 conv2 (N=64)
+    (1, 40, 128, 32, 3, 1, 1, 40, 0, 1, False),    # head conv 128->32 (+ReLU), N=32 tile
+    (5, 12, 768, 256, 3, 1, 1, 12, 0, 0, False),   # layer4_rn (small map, K=6912)
+])
+def test_conv_implicit_gemm(dtype, case):
+    B, H, Cin, Cout, k, stride, pad, Ho, a_relu, act, res = case
+    X = rnd(B, H, H, Cin, dtype=dtype, seed=6)
+    Wt = rnd(Cout, k, k, Cin, dtype=dtype, scale=(k * k * Cin) ** -0.5, seed=7)
+    bias = torch.randn(Cout, device=DEV) * 0.1
+    R = rnd(B, Ho, Ho, Cout, dtype=dtype, seed=8) if res else None
+    ref = conv_ref(X, Wt, bias, stride, pad, pad, Ho, Ho, a_relu)
+    if act == 1:
+        ref = F.relu(ref)
+    if res:
+        ref = ref + R.float()
+    got = op_conv(dtype, X, Wt, bias, R, stride, pad, pad, Ho, Ho, a_relu, act)
+    assert rel_err(got.float(), ref) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,S", [(1, 577), (3, 577), (2, 64), (1, 200)])
+def test_attention(dtype, B, S):
+    lib = load_library()
+    H = 12
+    qkv = rnd(B * S, 3 * H * 64, dtype=dtype, seed=9)
+    # spike a few keys so the running max really jumps between tiles (online-softmax rescale path)
+    q3 = qkv.view(B, S, 3, H, 64)
+    q3[:, S // 2, 1] *= 6.0
+    q3[:, S - 1, 1] *= 4.0
+    out = torch.empty(B * S, H * 64, device=DEV, dtype=TDT[dtype])
+    assert lib.dptx_op_attention(DTYPES[dtype], ptr(qkv), ptr(out), B, S, H, stream()) == 0
+    q, k, v = [t.permute(0, 2, 1, 3).float() for t in q3.unbind(2)]
+    att = ((q @ k.transpose(-1, -2)) * 0.125).softmax(-1)
+    ref = (att @ v).permute(0, 2, 1, 3).reshape(B * S, H * 64)
+    # P is rounded to 16 bit before the PV product: allow 2x the output-rounding budget
+    assert rel_err(out.float(), ref) < 2 * OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_layernorm(dtype):
+    lib = load_library()
+    M, C = 1155, 768
+    x = torch.randn(M, C, device=DEV) * 3 + 0.7
+    g, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+    y = torch.empty(M, C, device=DEV, dtype=TDT[dtype])
+    assert lib.dptx_op_layernorm(DTYPES[dtype], ptr(x), ptr(g), ptr(b), ptr(y), M, C, 1e-6, stream()) == 0
+    assert rel_err(y.float(), F.layer_norm(x, (C,), g, b, 1e-6)) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,HW,C,relu,res", [(2, 9216, 64, 1, False), (2, 2304, 128, 1, False), (3, 576, 1024, 1, True),
+                                              (1, 36864, 64, 0, False), (2, 9216, 256, 1, True), (2, 2304, 512, 0, False)])
+def test_groupnorm(dtype, B, HW, C, relu, res):
+    lib = load_library()
+    X = rnd(B, HW, C, dtype=dtype, seed=10) * 2 + 0.5
+    X = X.to(TDT[dtype])
+    g, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+    R = rnd(B, HW, C, dtype=dtype, seed=11) if res else None
+    Y = torch.empty_like(X)
+    scratch = torch.empty(B * 144 * 64, device=DEV)
+    assert lib.dptx_op_groupnorm(DTYPES[dtype], ptr(X), ptr(g), ptr(b), ptr(R), ptr(Y), B, HW, C, relu, 1e-5, ptr(scratch), stream()) == 0
+    ref = F.group_norm(X.float().permute(0, 2, 1), 32, g, b, 1e-5).permute(0, 2, 1)
+    if res:
+        ref = ref + R.float()
+    if relu:
+        ref = F.relu(ref)
+    assert rel_err(Y.float(), ref) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,C", [(2, 12, 256), (1, 96, 256), (2, 48, 128)])
+def test_upsample2x_align_corners(dtype, B, H, C):
+    lib = load_library()
+    X = rnd(B, H, H, C, dtype=dtype, seed=12)
+    Y = torch.empty(B, 2 * H, 2 * H, C, device=DEV, dtype=TDT[dtype])
+    assert lib.dptx_op_upsample2x(DTYPES[dtype], ptr(X), ptr(Y), B, H, H, C, stream()) == 0
+    ref = F.interpolate(X.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert rel_err(Y.float(), ref) < OUT_TOL[dtype]
