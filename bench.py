@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,6 +103,8 @@ def main():
             for k, (ms, n, macs) in eng.profile().items():
                 a = acc.setdefault(k, [0.0, n, macs])
                 a[0] += ms
+        if args.profile_dump:
+            eng.profile_dump(args.profile_dump)
         eng.set_profiling(False)
         P = max(1, args.profile_steps)
         breakdown = {k: {"ms_per_step": round(v[0] / P, 4), "launches": v[1], "executed_gmac_per_image": round(v[2] / 1e9, 3)}
@@ -120,21 +123,34 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.dpt_oracle import dpt_forward
-        ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
         sd = random_state_dict(0, C)
         xc = synthetic_input(1000, 4, args.task)
-        dpt_forward(sd, xc[:1])  # warm-up
+        ncpu = os.cpu_count() or 1
+        # oneDNN/MKL at batch 4 stop scaling (and then collapse) well before 256 threads: probe a few
+        # thread counts on one batch each and keep the fastest for the timed sample
+        best, best_t = None, None
+        for nt in sorted({min(ncpu, n) for n in (16, 32, 64, 128)}):
+            torch.set_num_threads(nt)
+            dpt_forward(sd, xc[:1])
+            t1 = time.perf_counter()
+            dpt_forward(sd, xc)
+            dt1 = time.perf_counter() - t1
+            if best_t is None or dt1 < best_t:
+                best, best_t = nt, dt1
+            if dt1 > 20:
+                break
+        torch.set_num_threads(best)
         t1 = time.perf_counter()
         n_img = 0
         while True:
             dpt_forward(sd, xc)
             n_img += xc.shape[0]
-            if time.perf_counter() - t1 > 12.0 or n_img >= 64:
+            if time.perf_counter() - t1 > 10.0 or n_img >= 64:
                 break
         dt_cpu = time.perf_counter() - t1
-        cpu_baseline = {"value": round(n_img / dt_cpu, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-                        "kind": "port", "sample": f"{n_img} images (batches of 4) of the same synthetic 384x384 workload, fp32"}
+        cpu_baseline = {"value": round(n_img / dt_cpu, 3), "unit": "images/s", "cores": best, "host_logical_cpus": ncpu,
+                        "kind": "port", "sample": f"{n_img} images (batches of 4) of the same synthetic 384x384 workload, fp32, "
+                                                  f"best of 16/32/64/128 threads"}
 
     if rank == 0:
         total_images = args.batch * world * args.steps

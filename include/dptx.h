@@ -125,6 +125,8 @@ int dptx_forward_info(dptx_handle h, int64_t* launches, double* algorithmic_macs
 int dptx_set_profiling(dptx_handle h, int on);
 int dptx_profile_get(dptx_handle h, int32_t category, double* ms, int64_t* launches,
                      double* macs_per_image);
+/* Writes "idx,category,name,ms" for every launch of the last profiled forward. */
+int dptx_profile_dump(dptx_handle h, const char* path);
 
 const char* dptx_last_error(dptx_handle h);
 const char* dptx_version(void);

@@ -10,6 +10,10 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));  // native 16-B register value (HIP's uint4
+                                                                // is a struct: arrays of it can end up in scratch)
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+
 constexpr int DT_BF16 = 0;
 constexpr int DT_FP16 = 1;
 
@@ -31,6 +35,10 @@ template <> struct T16<DT_BF16> {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
+  static __device__ __forceinline__ f32x16_t mfma32(u32x4_t a, u32x4_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
 };
 
 template <> struct T16<DT_FP16> {
@@ -45,6 +53,10 @@ template <> struct T16<DT_FP16> {
     return __builtin_bit_cast(uint32_t, v);
   }
   static __device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16_t mfma32(u32x4_t a, u32x4_t b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
                                                   __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
@@ -70,10 +82,16 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
-// ReLU on two packed 16-bit floats (bf16 or fp16: sign bit is bit 15 of each half).
+// ReLU on two packed 16-bit floats (bf16 or fp16).  Both are sign-magnitude, so as int16 a
+// negative float is a negative integer and a positive float keeps its bits: max(x, 0) as packed
+// int16 is exactly ReLU (one v_pk_max_i16).
 __device__ __forceinline__ uint32_t relu2(uint32_t v) {
-  uint32_t m = ((v >> 15) & 0x00010001u) * 0xffffu;
-  return v & ~m;
+  const s16x2_t z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, v), z));
+}
+__device__ __forceinline__ u32x4_t relu8(u32x4_t v) {
+  v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w);
+  return v;
 }
 __device__ __forceinline__ uint4 relu8(uint4 v) {
   v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w);

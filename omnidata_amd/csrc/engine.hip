@@ -226,6 +226,7 @@ struct dptx_engine {
   bool profiling = false;
   std::vector<hipEvent_t> events;
   std::vector<int> event_cat;
+  std::vector<std::string> event_name;
   double cat_ms[4] = {0, 0, 0, 0};
   int64_t cat_launches[4] = {0, 0, 0, 0};
   double cat_macs[4] = {0, 0, 0, 0};
@@ -368,6 +369,7 @@ struct Run {
       }
       (void)hipEventRecord(e->events[i], st);
       e->event_cat.push_back(cat);
+      e->event_name.emplace_back(w);
     }
   }
   void tap(const char* name, const void* p, int64_t h, int64_t w, int64_t c, bool fp32 = false) {
@@ -383,6 +385,7 @@ struct Run {
     p.M = B * Hout * Wout; p.N = Cout; p.K = ksz * ksz * Cin; p.ldw = p.K;
     p.a_rpi = Hout * Wout; p.Wout = Wout; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.a_pix_stride = Cin;
     p.a_img_stride = (long long)Hin * Win * Cin; p.a_off = 0;
+    p.a_bytes = (long long)B * Hin * Win * Cin * 2;
     p.ksz = ksz; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
     p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = Cout;
     p.act = act; p.a_relu = a_relu;
@@ -418,6 +421,7 @@ int Run::forward(const float* x, float* y) {
   E->exec_macs = 0.0;
   for (int c = 0; c < 4; ++c) E->cat_macs[c] = 0.0;
   E->event_cat.clear();
+  E->event_name.clear();
   if (E->profiling) {
     if (E->events.empty()) {
       hipEvent_t ev;
@@ -833,6 +837,23 @@ int dptx_profile_get(dptx_handle h, int32_t category, double* ms, int64_t* launc
   return DPTX_OK;
 }
 
+int dptx_profile_dump(dptx_handle h, const char* path) {
+  if (!h || !path) return DPTX_E_INVALID;
+  if (h->event_cat.empty()) return h->fail(DPTX_E_INVALID, "no profiled forward recorded");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipEventSynchronize(h->events[h->event_cat.size()]));
+  FILE* fp = fopen(path, "w");
+  if (!fp) return h->fail(DPTX_E_INVALID, std::string("cannot open ") + path);
+  fprintf(fp, "idx,category,name,ms\n");
+  for (size_t i = 0; i < h->event_cat.size(); ++i) {
+    float dt = 0.f;
+    (void)hipEventElapsedTime(&dt, h->events[i], h->events[i + 1]);
+    fprintf(fp, "%zu,%d,%s,%.5f\n", i, h->event_cat[i], h->event_name[i].c_str(), dt);
+  }
+  fclose(fp);
+  return DPTX_OK;
+}
+
 // --------------------------------------------------------------------- op-level entry points
 int dptx_op_gemm(int32_t dtype, const void* A, const void* W, const float* bias, const void* R, void* C, int32_t M, int32_t N,
                  int32_t K, int32_t act, int32_t a_fp32, int32_t c_fp32, int32_t r_fp32, void* stream) {
@@ -850,6 +871,7 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
   p.M = B * Ho * Wo; p.N = Cout; p.K = ksize * ksize * Cin; p.ldw = p.K;
   p.a_rpi = Ho * Wo; p.Wout = Wo; p.Hin = H; p.Win = W; p.Cin = Cin; p.a_pix_stride = Cin;
   p.a_img_stride = (long long)H * W * Cin;
+  p.a_bytes = (long long)B * H * W * Cin * 2;
   p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act; p.a_relu = a_relu;
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;

@@ -1,22 +1,30 @@
-// gemm.hip -- implicit-GEMM MFMA kernel for every linear / 1x1 / 3x3 / 7x7(im2col'd) layer of
+// gemm.hip -- implicit-GEMM MFMA kernels for every linear / 1x1 / 3x3 / 7x7(im2col'd) layer of
 // DPT-Hybrid (SURVEY.md A.6 lists the 44 unique shapes).  gfx950 only.
 //
 //   C[M,N] = epilogue( gatherA[M,K] * W[N,K]^T )
 //
 // * v_mfma_f32_32x32x16_{bf16,f16}: a wave owns a (TM*32) x (TN*32) accumulator block.
-// * BK = 64: one k-tile of A / W is [rows][64] 16-bit = 128 B per row in LDS, 16-B chunks
-//   XOR-swizzled with ((row>>1)&7) so that the ds_read_b128 fragment reads (16 distinct rows
-//   per lane group, same k chunk) are bank-conflict free; ds_write_b128 of a staged row hits 8
-//   distinct chunks.
-// * register-staged double buffering: global loads of tile t+1 are issued before the MFMAs of
-//   tile t and written to the other LDS buffer after them; one barrier per k-tile.
-// * A is gathered as NHWC conv taps (zero outside the image), so dense GEMM, strided 1x1 and
-//   kxk convolutions share the loader; optional ReLU / fp32->16-bit conversion while staging.
+// * BK = 64: one k-tile of A / W is [rows][64] 16-bit = 128 B per row in LDS; the 16-B chunks of a
+//   row are XOR-swizzled with ((row>>1)&7), which makes the ds_read_b128 fragment reads (16
+//   distinct rows per lane group, same k chunk) bank-conflict free.
+// * gemm_glds_kernel (default): both operands stream HBM/L2 -> LDS with `buffer_load_dwordx4 ...
+//   lds` (no VGPR round trip, no ds_write).  The LDS image of a wave-instruction is lane-linear
+//   (8 rows x 128 B), so the swizzle is applied to the per-lane SOURCE chunk; out-of-image conv
+//   taps and rows >= M use an out-of-range buffer offset, which the hardware returns as zeros.
+//   Two LDS stages: the loads of tile t+1 are in flight while tile t is multiplied; one
+//   vmcnt(0)+barrier per k-tile.
+// * gemm_reg_kernel: register-staged variant of the same tiling, used when A is fp32 (the
+//   ProjectReadout GEMM reads the fp32 token stream and rounds while staging) or when the A
+//   buffer is too large for a 32-bit buffer offset.
+// * A is gathered as NHWC conv taps, so dense GEMM, strided 1x1 and kxk convolutions share the
+//   loader; optional ReLU on the A fragments (RCU pre-activation, one v_pk_max_i16 per dword).
 // * epilogue: accumulators -> LDS fp32 tile -> coalesced 16-B rows with fused bias, ReLU /
 //   erf-GELU, up to two residuals (16-bit or fp32, one may broadcast over images), 16-bit or
 //   fp32 output, optional row remap (token rows skip the cls slot).
 // * 1-D grid, XCD-aware bijective remap; n-tile fastest so the blocks of one XCD re-use the
 //   same A rows out of that XCD's L2.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -24,160 +32,36 @@ namespace dptx {
 
 constexpr int BK = 64;
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_FP32>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-  static_assert(TM >= 1 && TN >= 1, "tile");
-  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
-  constexpr int A_REGS = A_FP32 ? 2 : 1;
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
+// ----------------------------------------------------------------------------- shared pieces
+template <int DT, int TM, int TN, bool RELU_A>
+__device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int wm, int wn, int lr, int lh,
+                                         f32x16_t (&acc)[TM][TN]) {
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    const int chunk = 2 * ks + lh;
+    u32x4_t af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * (TM * 32) + i * 32 + lr;
+      af[i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      if (RELU_A) af[i] = relu8(af[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * (TN * 32) + j * 32 + lr;
+      bf[j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = T16<DT>::mfma32(af[i], bf[j], acc[i][j]);
+  }
+}
+
+template <int DT, int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
+                                         int tid, f32x16_t (&acc)[TM][TN]) {
   constexpr int CT_PITCH = BN + 4;  // floats
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  const int tiles_n = p.N / BN;
-  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int n0 = (wg % tiles_n) * BN;
-  const int m0 = (wg / tiles_n) * BM;
-
-  // ---- loader state -------------------------------------------------------------------
-  const int kc = tid & 7;   // 16-B chunk (8 elements) inside the 64-wide k tile
-  const int r0 = tid >> 3;  // 0..31
-  int a_iy0[A_PASSES], a_ix0[A_PASSES];
-  long long a_base[A_PASSES];
-#pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + r0 + 32 * i;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    const int img = mm / p.a_rpi;
-    const int rem = mm - img * p.a_rpi;
-    const int oy = rem / p.Wout;
-    const int ox = rem - oy * p.Wout;
-    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;  // invalid rows never pass the bounds test
-    a_ix0[i] = ox * p.stride - p.pad_l;
-    a_base[i] = (long long)img * p.a_img_stride + p.a_off + kc * 8;
-  }
-  const char* __restrict__ Ab = (const char*)p.A;
-  const uint16_t* __restrict__ Wb = (const uint16_t*)p.W;
-  long long w_off[B_PASSES];
-#pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (long long)(n0 + r0 + 32 * j) * p.ldw + kc * 8;
-
-  uint4 ra[A_PASSES * A_REGS];
-  uint4 rb[B_PASSES];
-
-  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k tile being LOADED
-
-  auto load_tile = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
-      const long long e = a_base[i] + ((long long)iy * p.Win + ix) * p.a_pix_stride + c0;
-      if constexpr (A_FP32) {
-        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-        if (valid) {
-          const uint4* src = (const uint4*)(Ab + e * 4);
-          lo = src[0];
-          hi = src[1];
-        }
-        ra[2 * i] = lo;
-        ra[2 * i + 1] = hi;
-      } else {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (valid) v = *(const uint4*)(Ab + e * 2);
-        ra[i] = v;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) rb[j] = *(const uint4*)(Wb + w_off[j] + k0);
-    // advance tap bookkeeping to the next tile
-    c0 += BK;
-    if (c0 >= p.Cin) {
-      c0 = 0;
-      if (++kx == p.ksz) { kx = 0; ++ky; }
-    }
-  };
-
-  auto store_tile = [&](int buf) {
-    char* sa = smem + buf * STAGE_BYTES;
-    char* sb = sa + BM * 128;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int row = r0 + 32 * i;
-      uint4 v;
-      if constexpr (A_FP32) {
-        const uint4 lo = ra[2 * i], hi = ra[2 * i + 1];
-        v.x = T16<DT>::pack2(__uint_as_float(lo.x), __uint_as_float(lo.y));
-        v.y = T16<DT>::pack2(__uint_as_float(lo.z), __uint_as_float(lo.w));
-        v.z = T16<DT>::pack2(__uint_as_float(hi.x), __uint_as_float(hi.y));
-        v.w = T16<DT>::pack2(__uint_as_float(hi.z), __uint_as_float(hi.w));
-      } else {
-        v = ra[i];
-      }
-      if (p.a_relu) v = relu8(v);
-      *(uint4*)(sa + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v;
-    }
-#pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) {
-      const int row = r0 + 32 * j;
-      *(uint4*)(sb + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rb[j];
-    }
-  };
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int lr = lane & 31, lh = lane >> 5;
-  auto compute_tile = [&](int buf) {
-    const char* sa = smem + buf * STAGE_BYTES;
-    const char* sb = sa + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int chunk = 2 * ks + lh;
-      uint4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (TM * 32) + i * 32 + lr;
-        af[i] = *(const uint4*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * (TN * 32) + j * 32 + lr;
-        bf[j] = *(const uint4*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = T16<DT>::mfma32(af[i], bf[j], acc[i][j]);
-    }
-  };
-
-  // ---- main loop ----------------------------------------------------------------------
-  const int nk = p.K / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) load_tile((kt + 1) * BK);
-    compute_tile(kt & 1);
-    if (more) store_tile((kt + 1) & 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: accumulators -> LDS fp32 tile -> coalesced rows ------------------------
   float* ct = (float*)smem;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -191,8 +75,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
       }
   __syncthreads();
 
-  constexpr int NCH = BN / 8;      // 8-column chunks per tile row
-  constexpr int RPP = 256 / NCH;   // tile rows per pass
+  constexpr int NCH = BN / 8;     // 8-column chunks per tile row
+  constexpr int RPP = 256 / NCH;  // tile rows per pass
   const int cn = tid % NCH;
   const int rr = tid / NCH;
   const int n = n0 + cn * 8;
@@ -272,6 +156,236 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------- direct-to-LDS kernel
+constexpr unsigned OOB = 0x80000000u;  // >= any buffer size we bind (a_bytes < 2^31): reads as zero
+
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer/LDS-DMA builtins exist only in the device pass
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = p.N / BN;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int n0 = (wg % tiles_n) * BN;
+  const int m0 = (wg / tiles_n) * BM;
+
+  // loader: thread (r0 = tid>>3, kc = tid&7) owns LDS chunk kc of rows r0 + 32*i and fetches the
+  // SOURCE chunk kc ^ ((r0>>1)&7)   ((row>>1)&7 is the same for every pass: 32*i leaves bits 1..3)
+  const int kc = tid & 7, r0 = tid >> 3;
+  const int sc = kc ^ ((r0 >> 1) & 7);
+  int a_iy0[A_PASSES], a_ix0[A_PASSES];
+  unsigned a_off[A_PASSES];  // byte offset of (img, iy0, ix0, source chunk), mod 2^32
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int img = mm / p.a_rpi;
+    const int rem = mm - img * p.a_rpi;
+    const int oy = rem / p.Wout;
+    const int ox = rem - oy * p.Wout;
+    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;  // rows >= M never pass the bounds test
+    a_ix0[i] = ox * p.stride - p.pad_l;
+    const long long e = (long long)img * p.a_img_stride + p.a_off +
+                        ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * 8;
+    a_off[i] = (unsigned)(ok ? e * 2 : 0);
+  }
+  unsigned w_off[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2);
+
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)((long long)p.N * p.ldw * 2), 0x00020000);
+
+  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k tile being LOADED (wave-uniform)
+
+#define DPTX_ISSUE_TILE(BUF, K0)                                                                                   \
+  do {                                                                                                             \
+    char* sa_ = smem + (BUF) * STAGE_BYTES + wave * 1024;                                                          \
+    char* sb_ = sa_ + BM * 128;                                                                                    \
+    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                         \
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
+      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
+      const unsigned vo = valid ? a_off[i] + tap_ : OOB;                                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(sa_ + i * 4096), 16, vo, 0, \
+                                               0, 0);                                                              \
+    }                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) {                                                         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(sb_ + j * 4096), 16,        \
+                                               w_off[j] + (unsigned)((K0) * 2), 0, 0, 0);                          \
+    }                                                                                                              \
+    c0 += BK;                                                                                                      \
+    if (c0 >= p.Cin) {                                                                                             \
+      c0 = 0;                                                                                                      \
+      if (++kx == p.ksz) { kx = 0; ++ky; }                                                                         \
+    }                                                                                                              \
+  } while (0)
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  DPTX_ISSUE_TILE(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed (every wave waits for its own DMA, then the barrier publishes all of
+    // them) and every wave is done reading the other stage, which the next DMA overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) DPTX_ISSUE_TILE((kt + 1) & 1, (kt + 1) * BK);
+    const char* sa = smem + (kt & 1) * STAGE_BYTES;
+    mma_tile<DT, TM, TN, RELU_A>(sa, sa + BM * 128, wm, wn, lr, lh, acc);
+  }
+#undef DPTX_ISSUE_TILE
+  __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
+  epilogue<DT, BM, BN, TM, TN>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+#endif
+}
+
+// -------------------------------------------------------------------- register-staged kernel
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_FP32>
+__global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+  constexpr int A_REGS = A_FP32 ? 2 : 1;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = p.N / BN;
+  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int n0 = (wg % tiles_n) * BN;
+  const int m0 = (wg / tiles_n) * BM;
+
+  const int kc = tid & 7, r0 = tid >> 3;
+  int a_iy0[A_PASSES], a_ix0[A_PASSES];
+  long long a_base[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int img = mm / p.a_rpi;
+    const int rem = mm - img * p.a_rpi;
+    const int oy = rem / p.Wout;
+    const int ox = rem - oy * p.Wout;
+    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
+    a_ix0[i] = ox * p.stride - p.pad_l;
+    a_base[i] = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + kc * 8;
+  }
+  const char* __restrict__ Ab = (const char*)p.A;
+  const uint16_t* __restrict__ Wb = (const uint16_t*)p.W;
+  long long w_off[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (long long)(n0 + r0 + 32 * j) * p.ldw + kc * 8;
+
+  u32x4_t ra[A_PASSES * A_REGS];
+  u32x4_t rb[B_PASSES];
+  int ky = 0, kx = 0, c0 = 0;
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+
+#define DPTX_LOAD_TILE(K0)                                                                           \
+  do {                                                                                               \
+    const long long tap_ = (long long)(ky * p.Win + kx) * p.a_pix_stride + c0;                       \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                           \
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                              \
+      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);       \
+      const long long e = a_base[i] + tap_;                                                          \
+      if constexpr (A_FP32) {                                                                        \
+        u32x4_t lo = zero4, hi = zero4;                                                              \
+        if (valid) {                                                                                 \
+          const u32x4_t* src = (const u32x4_t*)(Ab + e * 4);                                         \
+          lo = src[0];                                                                               \
+          hi = src[1];                                                                               \
+        }                                                                                            \
+        ra[2 * i] = lo;                                                                              \
+        ra[2 * i + 1] = hi;                                                                          \
+      } else {                                                                                       \
+        u32x4_t v = zero4;                                                                           \
+        if (valid) v = *(const u32x4_t*)(Ab + e * 2);                                                \
+        ra[i] = v;                                                                                   \
+      }                                                                                              \
+    }                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) rb[j] = *(const u32x4_t*)(Wb + w_off[j] + (K0)); \
+    c0 += BK;                                                                                        \
+    if (c0 >= p.Cin) {                                                                               \
+      c0 = 0;                                                                                        \
+      if (++kx == p.ksz) { kx = 0; ++ky; }                                                           \
+    }                                                                                                \
+  } while (0)
+
+#define DPTX_STORE_TILE(BUF)                                                                         \
+  do {                                                                                               \
+    char* sa_ = smem + (BUF) * STAGE_BYTES;                                                          \
+    char* sb_ = sa_ + BM * 128;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                           \
+      const int row = r0 + 32 * i;                                                                   \
+      u32x4_t v;                                                                                     \
+      if constexpr (A_FP32) {                                                                        \
+        const u32x4_t lo = ra[2 * i], hi = ra[2 * i + 1];                                            \
+        v.x = T16<DT>::pack2(__uint_as_float(lo.x), __uint_as_float(lo.y));                          \
+        v.y = T16<DT>::pack2(__uint_as_float(lo.z), __uint_as_float(lo.w));                          \
+        v.z = T16<DT>::pack2(__uint_as_float(hi.x), __uint_as_float(hi.y));                          \
+        v.w = T16<DT>::pack2(__uint_as_float(hi.z), __uint_as_float(hi.w));                          \
+      } else {                                                                                       \
+        v = ra[i];                                                                                   \
+      }                                                                                              \
+      if (p.a_relu) v = relu8(v);                                                                    \
+      *(u32x4_t*)(sa_ + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v;                             \
+    }                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) {                                           \
+      const int row = r0 + 32 * j;                                                                   \
+      *(u32x4_t*)(sb_ + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rb[j];                         \
+    }                                                                                                \
+  } while (0)
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  DPTX_LOAD_TILE(0);
+  DPTX_STORE_TILE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1) < nk;
+    if (more) DPTX_LOAD_TILE((kt + 1) * BK);
+    const char* sa = smem + (kt & 1) * STAGE_BYTES;
+    mma_tile<DT, TM, TN, false>(sa, sa + BM * 128, wm, wn, lr, lh, acc);
+    if (more) DPTX_STORE_TILE((kt + 1) & 1);
+    __syncthreads();
+  }
+#undef DPTX_LOAD_TILE
+#undef DPTX_STORE_TILE
+  epilogue<DT, BM, BN, TM, TN>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+}
+
+// --------------------------------------------------------------------------------- dispatch
 template <int BM, int BN>
 constexpr size_t gemm_smem_bytes() {
   constexpr size_t stage = 2 * (size_t)(BM + BN) * 128;
@@ -279,19 +393,47 @@ constexpr size_t gemm_smem_bytes() {
   return stage > ct ? stage : ct;
 }
 
+template <typename K>
+static void set_smem_attr(K k, size_t smem) {
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+
+static int gemm_variant() {  // DPTX_GEMM=reg forces the register-staged kernel (A/B experiments)
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("DPTX_GEMM");
+    v = (s && s[0] == 'r') ? 1 : 0;
+  }
+  return v;
+}
+
 template <int DT, int BM, int BN, int WM_, int WN_>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   constexpr size_t smem = gemm_smem_bytes<BM, BN>();
-  if (p.a_fp32) {
-    auto k = gemm_kernel<DT, BM, BN, WM_, WN_, true>;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_done = true; }
+  const bool glds = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
+                    gemm_variant() == 0;
+  if (glds) {
+    if (p.a_relu) {
+      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true>;
+      static bool done = false;
+      if (!done) { set_smem_attr(k, smem); done = true; }
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
+    } else {
+      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false>;
+      static bool done = false;
+      if (!done) { set_smem_attr(k, smem); done = true; }
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
+    }
+  } else if (p.a_fp32) {
+    auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, true>;
+    static bool done = false;
+    if (!done) { set_smem_attr(k, smem); done = true; }
     hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
   } else {
-    auto k = gemm_kernel<DT, BM, BN, WM_, WN_, false>;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_done = true; }
+    auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, false>;
+    static bool done = false;
+    if (!done) { set_smem_attr(k, smem); done = true; }
     hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
   }
   return hipGetLastError();
@@ -300,13 +442,12 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
 template <int DT>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
-  const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256, m64 = (p.M + 63) / 64;
+  const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
   if (p.N % 128 == 0 && m128 * (p.N / 128) >= 448) return launch_cfg<DT, 128, 128, 2, 2>(p, stream);
   if (p.N == 32) return launch_cfg<DT, 256, 32, 4, 1>(p, stream);
   if (p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, 256, 64, 4, 1>(p, stream);
   if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, 128, 64, 2, 2>(p, stream);
   if (p.N % 64 == 0) return launch_cfg<DT, 64, 64, 2, 2>(p, stream);
-  (void)m64;
   return hipErrorInvalidValue;
 }
 
@@ -316,6 +457,7 @@ void gemm_params_dense(GemmParams& p, int M, int N, int K) {
   p.a_rpi = M > 0 ? M : 1; p.Wout = p.a_rpi; p.Hin = 1; p.Win = p.a_rpi; p.Cin = K; p.a_pix_stride = K;
   p.a_img_stride = 0; p.a_off = 0; p.ksz = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0;
   p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = N;
+  p.a_bytes = (long long)M * K * 2;
 }
 
 hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream) {

@@ -22,6 +22,7 @@ struct GemmParams {
   int ldw;  // elements between rows of W (>= K; ProjectReadout uses half of a [768][1536] matrix)
   int a_rpi, Wout, Hin, Win, Cin, a_pix_stride;
   long long a_img_stride, a_off;
+  long long a_bytes;  // size of the A buffer in bytes (bounds of the buffer descriptor; glds path needs < 2^31)
   int ksz, stride, pad_t, pad_l;
   // C row of m: img = m / c_rpi, p = m % c_rpi -> row = img*c_img_rows + c_row_off + p
   int c_rpi, c_img_rows, c_row_off, ldc;

@@ -42,6 +42,7 @@ ABI = [
     ("dptx_forward_info", C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("dptx_set_profiling", C.c_int, [_vp, C.c_int]),
     ("dptx_profile_get", C.c_int, [_vp, _i32, C.POINTER(C.c_double), _i64p, C.POINTER(C.c_double)]),
+    ("dptx_profile_dump", C.c_int, [_vp, C.c_char_p]),
     ("dptx_last_error", C.c_char_p, [_vp]),
     ("dptx_version", C.c_char_p, []),
     ("dptx_op_gemm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -188,6 +189,9 @@ class Engine:
             self._check(self.lib.dptx_profile_get(self.h, i, C.byref(ms), C.byref(n), C.byref(macs)), "profile_get")
             out[name] = (ms.value, n.value, macs.value)
         return out
+
+    def profile_dump(self, path: str):
+        self._check(self.lib.dptx_profile_dump(self.h, path.encode()), "profile_dump")
 
     def info(self) -> Tuple[int, float, float]:
         n, a, e = C.c_int64(), C.c_double(), C.c_double()

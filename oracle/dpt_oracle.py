@@ -37,6 +37,19 @@ import torch.nn.functional as F
 
 Tensor = torch.Tensor
 
+
+def oracle_threads(cap: int = 32) -> int:
+    """Threads for the CPU oracle: oneDNN/MKL convs at batch 1-4 get SLOWER past a few dozen
+    threads (a 256-thread run on the 2x64-core GPU host took 28 s/image), so cap them."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, cap))
+    torch.set_num_threads(n)
+    return n
+
 # ResNetV2 hybrid backbone geometry (timm vit_base_r50_s16_384: layers=(3,4,9))
 STAGE_DEPTHS = (3, 4, 9)
 STAGE_OUT = (256, 512, 1024)

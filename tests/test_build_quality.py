@@ -1,0 +1,37 @@
+"""Static checks on the compiled gfx950 code objects (hipcc cross-compiles here, no GPU needed):
+no kernel may use scratch memory (a staging array that falls out of registers serialises every
+global load behind s_waitcnt vmcnt(0) -- this happened once) and the hot kernels must contain the
+instructions the design relies on."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "omnidata_amd", "csrc")
+
+
+def disasm(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    "-o", str(out), os.path.join(CSRC, src)], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return out.read_text()
+
+
+@pytest.mark.parametrize("src", ["gemm.hip", "attention.hip", "norm.hip", "misc.hip"])
+def test_no_scratch_no_spills(src, tmp_path):
+    s = disasm(src, tmp_path)
+    names = re.findall(r"^\s+\.name:\s+(\S+)", s, flags=re.M)
+    priv = re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", s, flags=re.M)
+    spills = re.findall(r"^\s+\.vgpr_spill_count:\s+(\d+)", s, flags=re.M)
+    assert names and len(priv) >= 1
+    assert all(int(p) == 0 for p in priv), dict(zip(names, priv))
+    assert all(int(p) == 0 for p in spills)
+    assert "scratch_" not in s
+    if src == "gemm.hip":
+        assert "v_mfma_f32_32x32x16_bf16" in s and "v_mfma_f32_32x32x16_f16" in s
+        assert re.search(r"buffer_load_dwordx4 .* lds", s), "direct-to-LDS staging missing"
+        assert "v_pk_max_i16" in s  # packed ReLU on the A fragments
+    if src == "attention.hip":
+        assert "v_mfma_f32_32x32x16_bf16" in s and "v_exp_f32" in s
