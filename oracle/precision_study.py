@@ -57,3 +57,25 @@ if __name__ == "__main__":
             d = (y - ref).abs()
             print(f"{task:6s} {str(dt):15s} max|d|={d.max():.3e} rms={d.pow(2).mean().sqrt():.3e} "
                   f"p99.9={d.flatten().kthvalue(int(0.999 * d.numel())).values:.3e} (out std {ref.std():.3f})")
+
+
+def stage_errors(dtype, names=("stem", "s0", "s1", "s2", "tok0", "blk11", "l3", "l4", "p4", "p1", "h0", "h1")):
+    """rms-relative error of the emulated 16-bit-operand forward at every stage tap."""
+    import oracle.dpt_oracle as OO
+    sd = random_state_dict(0, 3)
+    x = synthetic_input(0, 1, "normal")
+    ref = {}
+    OO.dpt_forward(sd, x, ref)
+    got = {}
+    r = lambda t: t.to(dtype).float()
+    conv0, lin0 = F.conv2d, F.linear
+    class Fp:
+        def __getattr__(self, n):
+            return {"conv2d": lambda a, w, b=None, *aa, **k: conv0(r(a), r(w), b, *aa, **k),
+                    "linear": lambda a, w, b=None: lin0(r(a), r(w), b)}.get(n, getattr(F, n))
+    OO.F = Fp()
+    try:
+        OO.dpt_forward(sd, x, got)
+    finally:
+        OO.F = F
+    return {n: float((got[n] - ref[n]).pow(2).mean().sqrt() / ref[n].pow(2).mean().sqrt()) for n in names}

@@ -25,9 +25,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # (max-abs, rms) budget on the final [0,1]-range output vs the fp32 oracle
 E2E_TOL = {"bf16": (8e-2, 1.6e-2), "fp16": (1.2e-2, 2.5e-3)}
-# rms error / rms value allowed at every stage tap: operand rounding (2^-9 / 2^-12 per operand)
-# accumulated over the ~50 GEMMs upstream of the deepest tap
-STAGE_RMS_REL = {"bf16": 8e-2, "fp16": 1e-2}
+# rms error / rms value allowed at every stage tap.  The emulated floor (operand rounding only,
+# oracle/precision_study.py:stage_errors) peaks at ResNet stage 2 with these synthetic weights:
+# bf16 1.15e-1, fp16 1.6e-2; the engine additionally rounds conv outputs before GroupNorm and
+# measured 1.30e-1 / 1.9e-2.  Budget = ~1.5x the emulated floor.
+STAGE_RMS_REL = {"bf16": 1.7e-1, "fp16": 2.5e-2}
 _cache, _oracle = {}, {}
 
 
