@@ -1,0 +1,84 @@
+"""N>1 path on CPU: world_size-2 gloo.  Rank 0 folds/packs the weights (host-only handle), the
+packed blob is broadcast, rank 1 checks it equals its own packing; batch sharding covers the
+global batch exactly once.  No GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from omnidata_amd.dist import broadcast_blob, shard_range
+        from omnidata_amd.engine import Engine
+        from omnidata_amd.weights import random_state_dict
+        eng = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=None)   # host-only handle
+        nbytes = eng.packed_bytes
+        blob = None
+        if rank == 0:
+            eng.load_state_dict(random_state_dict(11, 3))
+            blob = torch.from_numpy(eng.export_packed_host())
+        got = broadcast_blob(blob, nbytes, torch.device("cpu"), src=0)
+        if rank != 0:   # the receiving rank packs the same seed itself and must get identical bytes
+            eng.load_state_dict(random_state_dict(11, 3))
+            assert np.array_equal(got.numpy(), eng.export_packed_host())
+        # sharding: every image of a global batch is owned by exactly one rank
+        for gb in (64, 65, 7, 1):
+            lo, hi = shard_range(gb, rank, world)
+            t = torch.zeros(gb, dtype=torch.int32)
+            t[lo:hi] = 1
+            dist.all_reduce(t)
+            assert bool((t == 1).all())
+        # max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == float(world)
+        q.put((rank, "ok", int(got.numel())))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_weight_broadcast_and_sharding_world2(built_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] == "ok" for r in res), res
+    assert res[0][2] == res[1][2] > 200e6
+
+
+def test_shard_range_properties():
+    from omnidata_amd.dist import shard_range
+    for world in (1, 2, 3, 8):
+        for gb in (0, 1, 7, 32, 255, 256):
+            spans = [shard_range(gb, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

