@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--task", default="normal", choices=["normal", "depth"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")

@@ -25,7 +25,7 @@ def main(argv=None):
     parser.add_argument("--output_path", dest="output_path", help="path to where output image should be stored")
     parser.add_argument("--weights", default=None, help="checkpoint path (default ./pretrained_models/omnidata_dpt_<task>_v2.ckpt)")
     parser.add_argument("--random-weights", type=int, default=None, metavar="SEED", help="seeded synthetic weights (offline)")
-    parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "bf16x3"])
     args = parser.parse_args(argv)
 
     if args.task not in ("normal", "depth"):

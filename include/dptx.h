@@ -37,8 +37,11 @@ enum {
   DPTX_E_ALLOC = -5
 };
 
-/* arithmetic type of the MFMA operands and of the stored activations */
-enum { DPTX_DTYPE_BF16 = 0, DPTX_DTYPE_FP16 = 1 };
+/* arithmetic type of the MFMA operands and of the stored activations.
+ * BF16X3 is the high-precision mode: every 16-bit tensor is a pair of bf16 planes (hi, lo = x - hi,
+ * 16 significand bits) and every product is 3 MFMAs (lo*hi + hi*lo + hi*hi) with fp32 accumulate:
+ * ~3x the MFMA work and 2x the activation bytes, meets 1e-3 abs against the fp32 reference. */
+enum { DPTX_DTYPE_BF16 = 0, DPTX_DTYPE_FP16 = 1, DPTX_DTYPE_BF16X3 = 2 };
 /* dtype of caller-side image / result buffers */
 enum { DPTX_IO_FP32 = 0 };
 
@@ -133,6 +136,11 @@ const char* dptx_version(void);
 
 /* ---- op-level entry points (unit tests + micro-benchmarks of the individual kernels) ----
  * dtype: DPTX_DTYPE_*.  All pointers are device pointers; row-major / NHWC. */
+
+/* For dtype = DPTX_DTYPE_BF16X3 the op entry points read/write hi/lo plane pairs: the lo plane of
+ * every activation (weight) tensor lies act_plane_elems (w_plane_elems) 16-bit elements after its
+ * hi plane.  Process-global, test use only. */
+int dptx_op_set_planes(int64_t act_plane_elems, int64_t w_plane_elems);
 
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+R); A,W,C,R 16-bit `dtype`; bias fp32 or NULL;
  * act: 0 none, 1 relu, 2 gelu(erf); c_fp32/r_fp32 select fp32 C / R. */

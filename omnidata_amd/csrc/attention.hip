@@ -30,10 +30,13 @@ __device__ __forceinline__ int vt_pos(int key) {  // swap bits 2 and 3
   return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
 }
 
-template <int DT>
+// PL == 2 (bf16x3 mode): q/k/v/p are hi+lo bf16 plane pairs and every product is 3 MFMAs
+// (lo*hi + hi*lo + hi*hi); `plane` is the element distance between the planes of qkv / out.
+template <int DT, int PL>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                           int S, int H) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * ATT_STAGE];
+                                                           int S, int H, long long plane) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x PL x (K tile + V^T tile)
+  constexpr int STAGE = ATT_STAGE * PL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
@@ -46,46 +49,52 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   // Q fragments (B operand: lane = query column, 8 consecutive d per k-step)
   const int q = blockIdx.x * 128 + wave * 32 + lr;
   const int qc = q < S ? q : S - 1;
-  uint4 qf[4];
+  uint4 qf[4], ql[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const uint4*)(qbase + (row0 + qc) * ld + ks * 16 + lh * 8);
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *(const uint4*)(qbase + (row0 + qc) * ld + ks * 16 + lh * 8);
+    if (PL == 2) ql[ks] = *(const uint4*)(qbase + plane + (row0 + qc) * ld + ks * 16 + lh * 8);
+  }
 
   // staging: thread t loads 16 B (d chunk t&7) of K for keys (t>>3), (t>>3)+32 and of V for the
   // adjacent key pair 2*(t>>3), 2*(t>>3)+1 (adjacent keys stay adjacent under vt_pos)
   const int kc = tid & 7, kr = tid >> 3;
-  uint4 rk[2], rv[2];
-  auto load_kv = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = t * ATT_KT + kr + 32 * i;
-      const int vkey = t * ATT_KT + 2 * kr + i;
-      uint4 k4 = make_uint4(0, 0, 0, 0), v4 = k4;
-      if (key < S) k4 = *(const uint4*)(kbase + (row0 + key) * ld + kc * 8);
-      if (vkey < S) v4 = *(const uint4*)(vbase + (row0 + vkey) * ld + kc * 8);
-      rk[i] = k4;
-      rv[i] = v4;
-    }
-  };
-  auto store_kv = [&](int buf) {
-    char* sk = smem + buf * ATT_STAGE;
-    char* sv = sk + ATT_K_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = kr + 32 * i;
-      *(uint4*)(sk + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rk[i];
-    }
-    const int key_l = 2 * kr;  // even key of the pair, 0..62
-    const int pos = (key_l & 32) | vt_pos(key_l & 31);
-    const uint32_t w0[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
-    const uint32_t w1[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const uint32_t a = (e & 1) ? (w0[e >> 1] >> 16) : (w0[e >> 1] & 0xffffu);
-      const uint32_t c = (e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu);
-      const int d = kc * 8 + e;
-      *(uint32_t*)(sv + d * 128 + ((((pos >> 3) ^ ((d >> 1) & 7))) << 4) + (pos & 7) * 2) = a | (c << 16);
-    }
-  };
+  u32x4_t rk[2 * PL], rv[2 * PL];  // [plane][i]
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+#define ATT_LOAD_KV(T)                                                                        \
+  do {                                                                                        \
+    _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) {                                       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+        const int key = (T) * ATT_KT + kr + 32 * i;                                           \
+        const int vkey = (T) * ATT_KT + 2 * kr + i;                                           \
+        u32x4_t k4 = zero4, v4 = zero4;                                                       \
+        if (key < S) k4 = *(const u32x4_t*)(kbase + pl * plane + (row0 + key) * ld + kc * 8); \
+        if (vkey < S) v4 = *(const u32x4_t*)(vbase + pl * plane + (row0 + vkey) * ld + kc * 8); \
+        rk[pl * 2 + i] = k4;                                                                  \
+        rv[pl * 2 + i] = v4;                                                                  \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
+#define ATT_STORE_KV(BUF)                                                                     \
+  do {                                                                                        \
+    _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) {                                       \
+      char* sk = smem + (BUF) * STAGE + pl * ATT_STAGE;                                       \
+      char* sv = sk + ATT_K_BYTES;                                                            \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
+        const int row = kr + 32 * i;                                                          \
+        *(u32x4_t*)(sk + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rk[pl * 2 + i];        \
+      }                                                                                       \
+      const int key_l = 2 * kr;                                                               \
+      const int pos = (key_l & 32) | vt_pos(key_l & 31);                                      \
+      const u32x4_t w0 = rv[pl * 2], w1 = rv[pl * 2 + 1];                                     \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                         \
+        const uint32_t a = (e & 1) ? (w0[e >> 1] >> 16) : (w0[e >> 1] & 0xffffu);             \
+        const uint32_t c = (e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu);             \
+        const int d = kc * 8 + e;                                                             \
+        *(uint32_t*)(sv + d * 128 + ((((pos >> 3) ^ ((d >> 1) & 7))) << 4) + (pos & 7) * 2) = a | (c << 16); \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
 
   f32x16_t o[2];
 #pragma unroll
@@ -94,13 +103,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   const float cexp = 0.125f * 1.4426950408889634f;  // softmax scale folded into exp2
 
   const int ntiles = (S + ATT_KT - 1) / ATT_KT;
-  load_kv(0);
-  store_kv(0);
+  ATT_LOAD_KV(0);
+  ATT_STORE_KV(0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1) < ntiles;
-    if (more) load_kv(t + 1);
-    const char* sk = smem + (t & 1) * ATT_STAGE;
+    if (more) ATT_LOAD_KV(t + 1);
+    const char* sk = smem + (t & 1) * STAGE;
     const char* sv = sk + ATT_K_BYTES;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -111,7 +120,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       for (int ks = 0; ks < 4; ++ks) {
         const int row = sub * 32 + lr;
         const int chunk = 2 * ks + lh;
-        const uint4 kf = *(const uint4*)(sk + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        const int koff = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        const uint4 kf = *(const uint4*)(sk + koff);
+        if (PL == 2) {
+          const uint4 kl = *(const uint4*)(sk + ATT_STAGE + koff);
+          s = T16<DT>::mfma32(kl, qf[ks], s);
+          s = T16<DT>::mfma32(kf, ql[ks], s);
+        }
         s = T16<DT>::mfma32(kf, qf[ks], s);
       }
       // s[r] = <K[key], Q[q]> with key = t*64 + sub*32 + (r&3) + 8*(r>>2) + 4*lh, q = this lane's column
@@ -138,23 +153,40 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       l_run = l_run * alpha + ps;  // per-half partial sum; halves are added at the end
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-      uint4 pf[2];
+      uint4 pf[2], pl2[2];
       pf[0] = pack8<DT>(pv);
       pf[1] = pack8<DT>(pv + 8);
+      if (PL == 2) {
+        float ph[16];
+        unpack8<DT>(pf[0], ph);
+        unpack8<DT>(pf[1], ph + 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ph[r] = pv[r] - ph[r];
+        pl2[0] = pack8<DT>(ph);
+        pl2[1] = pack8<DT>(ph + 8);
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int drow = dt * 32 + lr;
           const int vchunk = sub * 4 + s2 * 2 + lh;
-          const uint4 vf = *(const uint4*)(sv + drow * 128 + ((vchunk ^ ((drow >> 1) & 7)) << 4));
+          const int voff = drow * 128 + ((vchunk ^ ((drow >> 1) & 7)) << 4);
+          const uint4 vf = *(const uint4*)(sv + voff);
+          if (PL == 2) {
+            const uint4 vl = *(const uint4*)(sv + ATT_STAGE + voff);
+            o[dt] = T16<DT>::mfma32(vl, pf[s2], o[dt]);
+            o[dt] = T16<DT>::mfma32(vf, pl2[s2], o[dt]);
+          }
           o[dt] = T16<DT>::mfma32(vf, pf[s2], o[dt]);
         }
       }
     }
-    if (more) store_kv((t + 1) & 1);
+    if (more) ATT_STORE_KV((t + 1) & 1);
     __syncthreads();
   }
+#undef ATT_LOAD_KV
+#undef ATT_STORE_KV
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -164,21 +196,35 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        const float v0 = o[dt][4 * g] * inv, v1 = o[dt][4 * g + 1] * inv, v2 = o[dt][4 * g + 2] * inv, v3 = o[dt][4 * g + 3] * inv;
         uint2 w;
-        w.x = T16<DT>::pack2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv);
-        w.y = T16<DT>::pack2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        w.x = T16<DT>::pack2(v0, v1);
+        w.y = T16<DT>::pack2(v2, v3);
         *(uint2*)(op + dt * 32 + 8 * g + 4 * lh) = w;
+        if (PL == 2) {
+          uint2 l;
+          l.x = T16<DT>::pack2(v0 - T16<DT>::tof((uint16_t)(w.x & 0xffffu)), v1 - T16<DT>::tof((uint16_t)(w.x >> 16)));
+          l.y = T16<DT>::pack2(v2 - T16<DT>::tof((uint16_t)(w.y & 0xffffu)), v3 - T16<DT>::tof((uint16_t)(w.y >> 16)));
+          *(uint2*)(op + plane + dt * 32 + 8 * g + 4 * lh) = l;
+        }
       }
   }
 }
 
-hipError_t launch_attention(int dtype, const void* qkv, void* out, int B, int S, int heads, hipStream_t stream) {
+hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, int heads, Planes pl, hipStream_t stream) {
   dim3 grid((S + 127) / 128, heads, B);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(attention_kernel<DT_BF16>, grid, dim3(256), 0, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(attention_kernel<DT_FP16>, grid, dim3(256), 0, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads);
-  else
+  if (mode == MODE_BF16)
+    hipLaunchKernelGGL((attention_kernel<DT_BF16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, 0ll);
+  else if (mode == MODE_FP16)
+    hipLaunchKernelGGL((attention_kernel<DT_FP16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, 0ll);
+  else if (mode == MODE_BF16X3) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)attention_kernel<DT_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE);
+      done = true;
+    }
+    hipLaunchKernelGGL((attention_kernel<DT_BF16, 2>), grid, dim3(256), 4 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, pl.act);
+  } else
     return hipErrorInvalidValue;
   return hipGetLastError();
 }

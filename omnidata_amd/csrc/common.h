@@ -17,6 +17,26 @@ typedef short s16x2_t __attribute__((ext_vector_type(2)));
 constexpr int DT_BF16 = 0;
 constexpr int DT_FP16 = 1;
 
+// Precision modes of the engine ("dtype" in the C ABI):
+//   0 bf16, 1 fp16 : one 16-bit value per element, one MFMA per product.
+//   2 bf16x3       : every 16-bit tensor is stored as TWO bf16 planes hi = bf16(x), lo = bf16(x - hi)
+//                    (16 significand bits); a product is A_hi*W_hi + A_lo*W_hi + A_hi*W_lo = 3 MFMAs
+//                    with fp32 accumulation.  The lo plane of a tensor lives at a fixed distance from
+//                    its hi plane: `Planes::act` elements for activations (second half of the arena),
+//                    `Planes::w` for packed GEMM weights (second half of the blob).
+constexpr int MODE_BF16 = 0, MODE_FP16 = 1, MODE_BF16X3 = 2;
+#define DPTX_DISPATCH_MODE(mode, ...)                                         \
+  switch (mode) {                                                             \
+    case ::dptx::MODE_BF16:   { constexpr int DT = ::dptx::DT_BF16, PL = 1; __VA_ARGS__; } break; \
+    case ::dptx::MODE_FP16:   { constexpr int DT = ::dptx::DT_FP16, PL = 1; __VA_ARGS__; } break; \
+    case ::dptx::MODE_BF16X3: { constexpr int DT = ::dptx::DT_BF16, PL = 2; __VA_ARGS__; } break; \
+    default: return hipErrorInvalidValue;                                     \
+  }
+struct Planes {
+  long long act;  // element (uint16) distance hi -> lo plane of an activation tensor
+  long long w;    // same for packed 16-bit weights
+};
+
 // 16-bit storage/MFMA-operand type traits.  DT = 0: bf16, 1: fp16.
 template <int DT> struct T16;
 
@@ -101,6 +121,41 @@ __device__ __forceinline__ uint4 relu8(uint4 v) {
 // erf-GELU (timm Mlp / ProjectReadout use nn.GELU(), the exact erf form).  erf via Abramowitz &
 // Stegun 7.1.26 (|abs err| < 1.5e-7; measured 4.7e-7 on gelu over [-12,12] in fp32): a dozen VALU
 // ops + v_exp_f32 + v_rcp_f32 instead of libm erff's ~40, which showed up in the fc1 epilogue.
+// 8 consecutive elements <-> floats, with optional hi/lo planes
+template <int DT, int PL>
+__device__ __forceinline__ void load8f(const uint16_t* p, long long plane, float* f) {
+  unpack8<DT>(*(const uint4*)p, f);
+  if (PL == 2) {
+    float g[8];
+    unpack8<DT>(*(const uint4*)(p + plane), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += g[e];
+  }
+}
+template <int DT, int PL>
+__device__ __forceinline__ void store8f(uint16_t* p, long long plane, const float* f) {
+  const uint4 hi = pack8<DT>(f);
+  *(uint4*)p = hi;
+  if (PL == 2) {
+    float h[8], l[8];
+    unpack8<DT>(hi, h);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) l[e] = f[e] - h[e];
+    *(uint4*)(p + plane) = pack8<DT>(l);
+  }
+}
+// ReLU of a hi/lo pair: sign(x) == sign(hi), so lo is zeroed wherever hi is negative
+__device__ __forceinline__ void relu8_planes(u32x4_t& hi, u32x4_t& lo) {
+  const s16x2_t z = {0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const s16x2_t h = __builtin_bit_cast(s16x2_t, hi[i]);
+    const s16x2_t neg = h >> 15;  // 0xFFFF where negative
+    lo[i] = lo[i] & ~__builtin_bit_cast(uint32_t, neg);
+    hi[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(h, z));
+  }
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));

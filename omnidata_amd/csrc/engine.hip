@@ -207,7 +207,10 @@ struct dptx_engine {
   std::vector<Spec> spec;
   std::unordered_map<std::string, size_t> spec_index;
   std::unordered_map<std::string, size_t> packed_off;  // byte offset inside the blob
-  size_t packed_bytes = 0;
+  size_t packed_bytes = 0;    // total blob bytes (hi blob [+ lo blob in bf16x3 mode])
+  size_t packed_single = 0;   // bytes of one plane of the blob
+  size_t arena_single = 0;    // bytes of one plane of the arena
+  Planes pl{0, 0};
   std::map<std::string, std::vector<float>> staged;  // fp32 tensors loaded so far
   std::vector<uint8_t> host_blob;
   bool finalized = false;  // host blob valid
@@ -293,7 +296,10 @@ void plan_arena(dptx_engine* e) {
   take(e->H0, B * 36864 * 128, 2);
   take(e->H0U, B * 147456 * 128, 2);
   take(e->H1, B * 147456 * 32, 2);
-  e->arena_bytes = off;
+  e->arena_single = off;
+  const int npl = e->cfg.dtype == DPTX_DTYPE_BF16X3 ? 2 : 1;
+  e->arena_bytes = off * npl;
+  e->pl.act = npl == 2 ? (long long)(off / 2) : 0;
 }
 
 // ------------------------------------------------------------------------------- packing
@@ -303,8 +309,17 @@ int pack_host(dptx_engine* e) {
     if (s.role != R_UNUSED && !e->staged.count(s.key)) missing += (missing.empty() ? "" : ", ") + s.key;
   if (!missing.empty()) return e->fail(DPTX_E_KEY, "missing tensors (strict load): " + missing);
   e->host_blob.assign(e->packed_bytes, 0);
-  const bool bf = e->cfg.dtype == DPTX_DTYPE_BF16;
-  auto cvt = [&](float x) { return bf ? f32_to_bf16(x) : f32_to_fp16(x); };
+  const bool bf = e->cfg.dtype != DPTX_DTYPE_FP16;
+  const bool x3 = e->cfg.dtype == DPTX_DTYPE_BF16X3;
+  const size_t lo_elems = e->packed_single / 2;  // uint16 distance hi -> lo plane
+  auto bf16_to_f32 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+  // writes element i of a 16-bit tensor (and its lo plane in bf16x3 mode)
+  auto put = [&](uint16_t* d16, size_t i, float x) {
+    if (!bf) { d16[i] = f32_to_fp16(x); return; }
+    const uint16_t hi = f32_to_bf16(x);
+    d16[i] = hi;
+    if (x3) d16[i + lo_elems] = f32_to_bf16(x - bf16_to_f32(hi));
+  };
   for (const auto& s : e->spec) {
     if (s.role == R_UNUSED) continue;
     const std::vector<float>& src = e->staged.at(s.key);
@@ -315,7 +330,7 @@ int pack_host(dptx_engine* e) {
     }
     uint16_t* d16 = (uint16_t*)dst;
     if (s.role == R_LINEAR) {
-      for (size_t i = 0; i < src.size(); ++i) d16[i] = cvt(src[i]);
+      for (size_t i = 0; i < src.size(); ++i) put(d16, i, src[i]);
       continue;
     }
     // convolution OIHW -> [O][kh][kw][I]; StdConv2dSame weights are standardised first
@@ -340,7 +355,7 @@ int pack_host(dptx_engine* e) {
         for (int kx = 0; kx < KW; ++kx)
           for (int i = 0; i < I; ++i) {
             const double wv = ((double)wo[((size_t)i * KH + ky) * KW + kx] - mean) * scale;
-            d16[(size_t)o * out_k + ((size_t)ky * KW + kx) * I + i] = cvt((float)wv);
+            put(d16, (size_t)o * out_k + ((size_t)ky * KW + kx) * I + i, (float)wv);
           }
     }
   }
@@ -388,13 +403,13 @@ struct Run {
     p.a_bytes = (long long)B * Hin * Win * Cin * 2;
     p.ksz = ksz; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
     p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = Cout;
-    p.act = act; p.a_relu = a_relu;
+    p.act = act; p.a_relu = a_relu; p.planes = e->pl;
     e->exec_macs += (double)p.M / B * p.N * p.K;
     e->cat_macs[0] += (double)p.M / B * p.N * p.K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
   }
 
-  void gn_stats(const void* X, float* part, int HW, int C) { chk(launch_gn_stats(dt, X, part, B, HW, C, st), "gn_stats", 2); }
+  void gn_stats(const void* X, float* part, int HW, int C) { chk(launch_gn_stats(dt, X, part, B, HW, C, e->pl, st), "gn_stats", 2); }
   void gn_apply(void* X, const std::string& nkey, float* part, int HW, int C, int relu, const void* R = nullptr,
                 const std::string& rkey = "", const float* rpart = nullptr) {
     GnParams g{};
@@ -402,7 +417,7 @@ struct Run {
     g.R = R;
     if (!rkey.empty()) { g.r_gamma = e->f(rkey + ".weight"); g.r_beta = e->f(rkey + ".bias"); g.r_partial = rpart; }
     g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = 1e-5f;
-    chk(launch_gn_apply(dt, g, st), nkey.c_str(), 2);
+    chk(launch_gn_apply(dt, g, e->pl, st), nkey.c_str(), 2);
   }
 
   // RCU (blocks.py:263-286): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
@@ -437,18 +452,18 @@ int Run::forward(const float* x, float* y) {
   float* part3 = (float*)E->a(E->part[3]);
 
   // ---- stem: conv7x7 s2 SAME (im2col + GEMM) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
-  chk(launch_im2col_stem(dt, x, E->a(E->col), B, IMG, IMG, st), "im2col_stem");
+  chk(launch_im2col_stem(dt, x, E->a(E->col), B, IMG, IMG, E->pl, st), "im2col_stem");
   {
     GemmParams p;
     gemm_params_dense(p, B * 36864, 64, STEM_K);
-    p.A = E->a(E->col); p.W = E->w(bp + "stem.conv.weight"); p.C = E->a(E->sraw);
+    p.A = E->a(E->col); p.W = E->w(bp + "stem.conv.weight"); p.C = E->a(E->sraw); p.planes = E->pl;
     E->exec_macs += 36864.0 * 64 * STEM_K;
     E->cat_macs[0] += 36864.0 * 64 * STEM_K;
     chk(launch_gemm(dt, p, st), "stem.conv", 0);
   }
   gn_stats(E->a(E->sraw), part0, 36864, 64);
   chk(launch_gn_relu_maxpool(dt, E->a(E->sraw), E->a(E->stem), E->f(bp + "stem.norm.weight"), E->f(bp + "stem.norm.bias"),
-                             part0, B, 192, 192, 64, 1e-5f, st),
+                             part0, B, 192, 192, 64, 1e-5f, E->pl, st),
       "stem.pool", 2);
   tap("stem", E->a(E->stem), 96, 96, 64);
 
@@ -496,7 +511,7 @@ int Run::forward(const float* x, float* y) {
     p.A = E->a(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
     p.bias = E->f(vp + "patch_embed.proj.bias");
     p.c_rpi = 576; p.c_img_rows = S_TOK; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
-    p.R2 = E->f(vp + "pos_embed"); p.r2_bcast = 1; p.r2_fp32 = 1;
+    p.R2 = E->f(vp + "pos_embed"); p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
     E->exec_macs += 576.0 * D_VIT * 1024;
     E->cat_macs[0] += 576.0 * D_VIT * 1024;
     chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
@@ -517,7 +532,7 @@ int Run::forward(const float* x, float* y) {
     GemmParams p;
     gemm_params_dense(p, M, N, K);
     p.A = A; p.a_fp32 = a_fp32; p.W = E->w(wkey); p.C = C; p.c_fp32 = c_fp32; p.bias = bias; p.act = act;
-    p.R1 = R1; p.r1_fp32 = r1_fp32;
+    p.R1 = R1; p.r1_fp32 = r1_fp32; p.planes = E->pl;
     E->exec_macs += (double)S_TOK * N * K;
     E->cat_macs[0] += (double)S_TOK * N * K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
@@ -528,12 +543,15 @@ int Run::forward(const float* x, float* y) {
     const std::string pp = "pretrained.act_postprocess" + std::to_string(n) + ".";
     float* clsb = (float*)E->a(E->clsb);
     chk(launch_readout_cls(dt, X, (long long)S_TOK * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT, D_VIT,
-                           E->f(pp + "0.project.0.bias"), clsb, B, D_VIT, D_VIT, st),
+                           E->f(pp + "0.project.0.bias"), clsb, B, D_VIT, D_VIT, E->pl, st),
         "readout_cls");
+    // the token GEMM reads a 16-bit image of the fp32 stream (Hn is free between blocks)
+    chk(launch_cast_f32(dt, X, E->a(E->Hn), (size_t)B * S_TOK * D_VIT, E->pl, st), "readout_cast");
     E->exec_macs += (double)D_VIT * D_VIT;  // per image
     void* R = (n == 3) ? E->a(E->R3) : E->a(E->R4);
     GemmParams p{};
-    p.A = X; p.a_fp32 = 1; p.W = E->w(pp + "0.project.0.weight"); p.ldw = 2 * D_VIT; p.C = R;
+    p.A = E->a(E->Hn); p.a_bytes = (long long)B * S_TOK * D_VIT * 2; p.planes = E->pl;
+    p.W = E->w(pp + "0.project.0.weight"); p.ldw = 2 * D_VIT; p.C = R;
     p.M = B * 576; p.N = D_VIT; p.K = D_VIT;
     p.a_rpi = 576; p.Wout = 576; p.Hin = 1; p.Win = 576; p.Cin = D_VIT; p.a_pix_stride = D_VIT;
     p.a_img_stride = (long long)S_TOK * D_VIT; p.a_off = D_VIT;  // skip the cls row
@@ -556,13 +574,13 @@ int Run::forward(const float* x, float* y) {
   // ---- 12 transformer blocks (timm Block; LN eps 1e-6) -----------------------------------
   for (int l = 0; l < 12; ++l) {
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
-    chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, st), "ln1", 2);
+    chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
     dense(E->a(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, E->a(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0);
-    chk(launch_attention(dt, E->a(E->QKV), E->a(E->AO), B, S_TOK, N_HEADS, st), "attention", 1);
+    chk(launch_attention(dt, E->a(E->QKV), E->a(E->AO), B, S_TOK, N_HEADS, E->pl, st), "attention", 1);
     E->exec_macs += 2.0 * N_HEADS * (double)S_TOK * S_TOK * 64;
     E->cat_macs[1] += 2.0 * N_HEADS * (double)S_TOK * S_TOK * 64;
     dense(E->a(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1);
-    chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, st), "ln2", 2);
+    chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln2", 2);
     dense(E->a(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, E->a(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0);
     dense(E->a(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1);
     {
@@ -603,7 +621,7 @@ int Run::forward(const float* x, float* y) {
     }
     rcu(p + "resConfUnit2.", sum, h, E->a(E->tA), E->a(E->tC), nullptr);
     conv(E->a(E->tC), h, h, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, h, FEAT, E->a(E->tA), E->f(p + "out_conv.bias"), 0, 0);
-    chk(launch_upsample2x(dt, E->a(E->tA), E->a(E->P[i - 1]), B, h, h, FEAT, st), "fusion.up");
+    chk(launch_upsample2x(dt, E->a(E->tA), E->a(E->P[i - 1]), B, h, h, FEAT, E->pl, st), "fusion.up");
     path = E->a(E->P[i - 1]);
     tap(p_names[i - 1], path, 2 * h, 2 * h, FEAT);
   }
@@ -612,11 +630,11 @@ int Run::forward(const float* x, float* y) {
   const std::string oc = "scratch.output_conv.";
   conv(path, 192, 192, FEAT, oc + "0.weight", 3, 1, 1, 1, 192, 192, 128, E->a(E->H0), E->f(oc + "0.bias"), 0, 0);
   tap("h0", E->a(E->H0), 192, 192, 128);
-  chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, 192, 192, 128, st), "head.up");
+  chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, 192, 192, 128, E->pl, st), "head.up");
   conv(E->a(E->H0U), 384, 384, 128, oc + "2.weight", 3, 1, 1, 1, 384, 384, 32, E->a(E->H1), E->f(oc + "2.bias"), 1, 0);
   tap("h1", E->a(E->H1), 384, 384, 32);
   chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), y, B, IMG * IMG, E->cfg.num_channels,
-                      E->cfg.non_negative, st),
+                      E->cfg.non_negative, E->pl, st),
       "head.out");
   E->exec_macs += 147456.0 * 32 * E->cfg.num_channels;
   E->last_batch = B;
@@ -646,7 +664,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (!out || !cfg) return DPTX_E_INVALID;
   *out = nullptr;
   if ((cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 4096 ||
-      (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16) || (cfg->ws_form != 0 && cfg->ws_form != 1))
+      (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16 && cfg->dtype != DPTX_DTYPE_BF16X3) ||
+      (cfg->ws_form != 0 && cfg->ws_form != 1))
     return DPTX_E_INVALID;
   dptx_engine* e = new (std::nothrow) dptx_engine();
   if (!e) return DPTX_E_ALLOC;
@@ -661,7 +680,9 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
       off += align_up(b, 256);
     }
   }
-  e->packed_bytes = off;
+  e->packed_single = off;
+  e->packed_bytes = off * (cfg->dtype == DPTX_DTYPE_BF16X3 ? 2 : 1);
+  e->pl.w = cfg->dtype == DPTX_DTYPE_BF16X3 ? (long long)(off / 2) : 0;
   plan_arena(e);
   if (cfg->device_id >= 0) {
     int n = 0;
@@ -794,7 +815,7 @@ int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_f
   } else {
     float* tmp = nullptr;
     HIPCHK(h, hipMalloc((void**)&tmp, n * 4));
-    hipError_t r = launch_to_f32(h->cfg.dtype, t.ptr, tmp, n, nullptr);
+    hipError_t r = launch_to_f32(h->cfg.dtype, t.ptr, tmp, n, h->pl, nullptr);
     if (r == hipSuccess) r = hipMemcpy(dst_host, tmp, n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     if (r != hipSuccess) return h->fail(DPTX_E_HIP, hipGetErrorString(r));
@@ -855,11 +876,19 @@ int dptx_profile_dump(dptx_handle h, const char* path) {
 }
 
 // --------------------------------------------------------------------- op-level entry points
+static Planes g_op_planes{0, 0};
+int dptx_op_set_planes(int64_t act_plane_elems, int64_t w_plane_elems) {
+  g_op_planes.act = act_plane_elems;
+  g_op_planes.w = w_plane_elems;
+  return DPTX_OK;
+}
+
 int dptx_op_gemm(int32_t dtype, const void* A, const void* W, const float* bias, const void* R, void* C, int32_t M, int32_t N,
                  int32_t K, int32_t act, int32_t a_fp32, int32_t c_fp32, int32_t r_fp32, void* stream) {
   GemmParams p;
   gemm_params_dense(p, M, N, K);
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.R1 = R; p.act = act; p.a_fp32 = a_fp32; p.c_fp32 = c_fp32; p.r1_fp32 = r_fp32;
+  p.planes = g_op_planes;
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
@@ -873,31 +902,31 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
   p.a_img_stride = (long long)H * W * Cin;
   p.a_bytes = (long long)B * H * W * Cin * 2;
   p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-  p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act; p.a_relu = a_relu;
+  p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act; p.a_relu = a_relu; p.planes = g_op_planes;
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
 int dptx_op_attention(int32_t dtype, const void* qkv, void* out, int32_t B, int32_t S, int32_t heads, void* stream) {
-  return launch_attention(dtype, qkv, out, B, S, heads, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+  return launch_attention(dtype, qkv, out, B, S, heads, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
 int dptx_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta, void* y, int32_t M, int32_t C,
                       float eps, void* stream) {
-  return launch_layernorm(dtype, x, gamma, beta, y, M, C, eps, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+  return launch_layernorm(dtype, x, gamma, beta, y, M, C, eps, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
 int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const float* beta, const void* R, void* Y, int32_t B,
                       int32_t HW, int32_t C, int32_t relu, float eps, void* scratch_f32, void* stream) {
-  hipError_t r = launch_gn_stats(dtype, X, (float*)scratch_f32, B, HW, C, (hipStream_t)stream);
+  hipError_t r = launch_gn_stats(dtype, X, (float*)scratch_f32, B, HW, C, g_op_planes, (hipStream_t)stream);
   if (r != hipSuccess) return DPTX_E_HIP;
   GnParams g{};
   g.X = X; g.Y = Y; g.gamma = gamma; g.beta = beta; g.partial = (float*)scratch_f32; g.R = R;
   g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = eps;
-  return launch_gn_apply(dtype, g, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+  return launch_gn_apply(dtype, g, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
 int dptx_op_upsample2x(int32_t dtype, const void* X, void* Y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
-  return launch_upsample2x(dtype, X, Y, B, H, W, C, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+  return launch_upsample2x(dtype, X, Y, B, H, W, C, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
 }  // extern "C"

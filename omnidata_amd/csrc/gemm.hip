@@ -33,32 +33,47 @@ namespace dptx {
 constexpr int BK = 64;
 
 // ----------------------------------------------------------------------------- shared pieces
-template <int DT, int TM, int TN, bool RELU_A>
-__device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int wm, int wn, int lr, int lh,
+template <int DT, int TM, int TN, bool RELU_A, int PL = 1>
+__device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_lo, int b_lo, int wm, int wn, int lr, int lh,
                                          f32x16_t (&acc)[TM][TN]) {
+  // a_lo / b_lo: byte distance of the lo-plane tiles inside the stage (PL == 2)
 #pragma unroll
   for (int ks = 0; ks < BK / 16; ++ks) {
     const int chunk = 2 * ks + lh;
-    u32x4_t af[TM], bf[TN];
+    u32x4_t af[TM], bf[TN], al[TM], bl[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wm * (TM * 32) + i * 32 + lr;
-      af[i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-      if (RELU_A) af[i] = relu8(af[i]);
+      const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+      af[i] = *(const u32x4_t*)(sa + off);
+      if (PL == 2) {
+        al[i] = *(const u32x4_t*)(sa + a_lo + off);
+        if (RELU_A) relu8_planes(af[i], al[i]);
+      } else if (RELU_A) {
+        af[i] = relu8(af[i]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = wn * (TN * 32) + j * 32 + lr;
-      bf[j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+      bf[j] = *(const u32x4_t*)(sb + off);
+      if (PL == 2) bl[j] = *(const u32x4_t*)(sb + b_lo + off);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = T16<DT>::mfma32(af[i], bf[j], acc[i][j]);
+      for (int j = 0; j < TN; ++j) {
+        if (PL == 2) {  // small cross terms first, then the leading term
+          acc[i][j] = T16<DT>::mfma32(al[i], bf[j], acc[i][j]);
+          acc[i][j] = T16<DT>::mfma32(af[i], bl[j], acc[i][j]);
+        }
+        acc[i][j] = T16<DT>::mfma32(af[i], bf[j], acc[i][j]);
+      }
   }
 }
 
-template <int DT, int BM, int BN, int TM, int TN>
+template <int DT, int BM, int BN, int TM, int TN, int PL = 1>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                          int tid, f32x16_t (&acc)[TM][TN]) {
   constexpr int CT_PITCH = BN + 4;  // floats
@@ -126,7 +141,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
       } else {
         float f[8];
-        unpack8<DT>(*(const uint4*)((const uint16_t*)p.R1 + off), f);
+        load8f<DT, PL>((const uint16_t*)p.R1 + off, p.planes.act, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += f[e];
       }
@@ -140,7 +155,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
       } else {
         float f[8];
-        unpack8<DT>(*(const uint4*)((const uint16_t*)p.R2 + off), f);
+        load8f<DT, PL>((const uint16_t*)p.R2 + off, p.planes.act, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += f[e];
       }
@@ -151,7 +166,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
       *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-      *(uint4*)((uint16_t*)p.C + coff) = pack8<DT>(v);
+      store8f<DT, PL>((uint16_t*)p.C + coff, p.planes.act, v);
     }
   }
 }
@@ -159,13 +174,15 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
 // ------------------------------------------------------------------- direct-to-LDS kernel
 constexpr unsigned OOB = 0x80000000u;  // >= any buffer size we bind (a_bytes < 2^31): reads as zero
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A, int PL>
+__global__ __launch_bounds__(256, PL == 2 ? 1 : 2) void gemm_glds_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer/LDS-DMA builtins exist only in the device pass
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
   constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
   constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  // stage image: [A hi][A lo (PL==2)][W hi][W lo (PL==2)]
+  constexpr int A_LO = BM * 128, B_BASE = PL * BM * 128, B_LO = BN * 128;
+  constexpr int STAGE_BYTES = PL * (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -204,16 +221,21 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2);
 
+  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)((long long)p.N * p.ldw * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
+  // lo planes (bf16x3 mode): same offsets, bases shifted by the plane distance
+  const __amdgpu_buffer_rsrc_t rsrcAl = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((uint16_t*)const_cast<void*>(p.A) + (PL == 2 ? p.planes.act : 0)), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcWl = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((uint16_t*)const_cast<void*>(p.W) + (PL == 2 ? p.planes.w : 0)), 0, w_bytes, 0x00020000);
 
   int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k tile being LOADED (wave-uniform)
 
 #define DPTX_ISSUE_TILE(BUF, K0)                                                                                   \
   do {                                                                                                             \
     char* sa_ = smem + (BUF) * STAGE_BYTES + wave * 1024;                                                          \
-    char* sb_ = sa_ + BM * 128;                                                                                    \
+    char* sb_ = sa_ + B_BASE;                                                                                      \
     const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                         \
       const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
@@ -221,10 +243,16 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
       const unsigned vo = valid ? a_off[i] + tap_ : OOB;                                                           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(sa_ + i * 4096), 16, vo, 0, \
                                                0, 0);                                                              \
+      if (PL == 2)                                                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcAl, (__attribute__((address_space(3))) void*)(sa_ + A_LO + i * 4096), \
+                                                 16, vo, 0, 0, 0);                                                 \
     }                                                                                                              \
     _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) {                                                         \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(sb_ + j * 4096), 16,        \
                                                w_off[j] + (unsigned)((K0) * 2), 0, 0, 0);                          \
+      if (PL == 2)                                                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcWl, (__attribute__((address_space(3))) void*)(sb_ + B_LO + j * 4096), \
+                                                 16, w_off[j] + (unsigned)((K0) * 2), 0, 0, 0);                    \
     }                                                                                                              \
     c0 += BK;                                                                                                      \
     if (c0 >= p.Cin) {                                                                                             \
@@ -250,11 +278,11 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
     __syncthreads();
     if (kt + 1 < nk) DPTX_ISSUE_TILE((kt + 1) & 1, (kt + 1) * BK);
     const char* sa = smem + (kt & 1) * STAGE_BYTES;
-    mma_tile<DT, TM, TN, RELU_A>(sa, sa + BM * 128, wm, wn, lr, lh, acc);
+    mma_tile<DT, TM, TN, RELU_A, PL>(sa, sa + B_BASE, A_LO, B_LO, wm, wn, lr, lh, acc);
   }
 #undef DPTX_ISSUE_TILE
   __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
-  epilogue<DT, BM, BN, TM, TN>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+  epilogue<DT, BM, BN, TM, TN, PL>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
 }
 
@@ -376,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
     const bool more = (kt + 1) < nk;
     if (more) DPTX_LOAD_TILE((kt + 1) * BK);
     const char* sa = smem + (kt & 1) * STAGE_BYTES;
-    mma_tile<DT, TM, TN, false>(sa, sa + BM * 128, wm, wn, lr, lh, acc);
+    mma_tile<DT, TM, TN, false, 1>(sa, sa + BM * 128, 0, 0, wm, wn, lr, lh, acc);
     if (more) DPTX_STORE_TILE((kt + 1) & 1);
     __syncthreads();
   }
@@ -386,9 +414,9 @@ __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
 }
 
 // --------------------------------------------------------------------------------- dispatch
-template <int BM, int BN>
+template <int BM, int BN, int PL>
 constexpr size_t gemm_smem_bytes() {
-  constexpr size_t stage = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t stage = 2 * (size_t)PL * (BM + BN) * 128;
   constexpr size_t ct = (size_t)BM * (BN + 4) * 4;
   return stage > ct ? stage : ct;
 }
@@ -407,47 +435,50 @@ static int gemm_variant() {  // DPTX_GEMM=reg forces the register-staged kernel 
   return v;
 }
 
-template <int DT, int BM, int BN, int WM_, int WN_>
+template <int DT, int PL, int BM, int BN, int WM_, int WN_>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-  constexpr size_t smem = gemm_smem_bytes<BM, BN>();
-  const bool glds = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
-                    gemm_variant() == 0;
-  if (glds) {
+  constexpr size_t smem = gemm_smem_bytes<BM, BN, PL>();
+  const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31);
+  if (PL == 2 && !glds_ok) return hipErrorInvalidValue;  // the 3-pass mode exists only on the direct-to-LDS path
+  if (glds_ok && (PL == 2 || gemm_variant() == 0)) {
     if (p.a_relu) {
-      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true>;
+      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL>;
       static bool done = false;
       if (!done) { set_smem_attr(k, smem); done = true; }
       hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
     } else {
-      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false>;
+      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
       static bool done = false;
       if (!done) { set_smem_attr(k, smem); done = true; }
       hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
     }
-  } else if (p.a_fp32) {
-    auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, true>;
-    static bool done = false;
-    if (!done) { set_smem_attr(k, smem); done = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
-  } else {
-    auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, false>;
-    static bool done = false;
-    if (!done) { set_smem_attr(k, smem); done = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
+  } else if constexpr (PL == 1) {
+    constexpr size_t smem1 = gemm_smem_bytes<BM, BN, 1>();
+    if (p.a_fp32) {
+      auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, true>;
+      static bool done = false;
+      if (!done) { set_smem_attr(k, smem1); done = true; }
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, p);
+    } else {
+      auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, false>;
+      static bool done = false;
+      if (!done) { set_smem_attr(k, smem1); done = true; }
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, p);
+    }
   }
   return hipGetLastError();
 }
 
-template <int DT>
+template <int DT, int PL>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
   const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
-  if (p.N % 128 == 0 && m128 * (p.N / 128) >= 448) return launch_cfg<DT, 128, 128, 2, 2>(p, stream);
-  if (p.N == 32) return launch_cfg<DT, 256, 32, 4, 1>(p, stream);
-  if (p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, 256, 64, 4, 1>(p, stream);
-  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, 128, 64, 2, 2>(p, stream);
-  if (p.N % 64 == 0) return launch_cfg<DT, 64, 64, 2, 2>(p, stream);
+  if (p.N % 128 == 0 && m128 * (p.N / 128) >= 448) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
+  if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1>(p, stream);
+  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 256, 64, 4, 1>(p, stream);
+  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
+  if (p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
   return hipErrorInvalidValue;
 }
 
@@ -460,10 +491,11 @@ void gemm_params_dense(GemmParams& p, int M, int N, int K) {
   p.a_bytes = (long long)M * K * 2;
 }
 
-hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream) {
+hipError_t launch_gemm(int mode, const GemmParams& p, hipStream_t stream) {
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 8 != 0) return hipErrorInvalidValue;
-  if (dtype == DT_BF16) return launch_dt<DT_BF16>(p, stream);
-  if (dtype == DT_FP16) return launch_dt<DT_FP16>(p, stream);
+  if (mode == MODE_BF16) return launch_dt<DT_BF16, 1>(p, stream);
+  if (mode == MODE_FP16) return launch_dt<DT_FP16, 1>(p, stream);
+  if (mode == MODE_BF16X3) return launch_dt<DT_BF16, 2>(p, stream);
   return hipErrorInvalidValue;
 }
 

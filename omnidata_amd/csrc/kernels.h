@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "common.h"
+
 namespace dptx {
 
 // One implicit-GEMM problem: C[M,N] = epilogue( gatherA[M,K] * W[N,K]^T ).
@@ -32,6 +34,7 @@ struct GemmParams {
   int a_relu;        // relu applied to A while staging (RCU pre-activation)
   int a_fp32;        // A elements are fp32 (converted while staging)
   int c_fp32, r1_fp32, r2_fp32;
+  Planes planes;  // hi->lo plane distances (bf16x3 mode only)
 };
 
 // Fills the "plain dense row-major" defaults for A [M,K] (lda = K) and C [M,N].
@@ -39,10 +42,10 @@ void gemm_params_dense(GemmParams& p, int M, int N, int K);
 // dtype 0 bf16 / 1 fp16.  Picks the tile configuration from (M, N).  Returns hipError_t.
 hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 
-hipError_t launch_attention(int dtype, const void* qkv, void* out, int B, int S, int heads, hipStream_t stream);
+hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, int heads, Planes pl, hipStream_t stream);
 
-hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, void* y,
-                            int M, int C, float eps, hipStream_t stream);
+hipError_t launch_layernorm(int mode, const float* x, const float* gamma, const float* beta, void* y,
+                            int M, int C, float eps, Planes pl, hipStream_t stream);
 
 // GroupNorm(32) on NHWC 16-bit: stats pass writes partial[B][chunks][32][2] fp32,
 // apply pass: Y = act( gn(X) + (R ? (r_gamma ? gn2(R) : R) : 0) ).  In-place (Y==X) allowed.
@@ -56,30 +59,32 @@ struct GnParams {
   float eps;
 };
 int gn_chunks(int HW);
-hipError_t launch_gn_stats(int dtype, const void* X, float* partial, int B, int HW, int C, hipStream_t stream);
-hipError_t launch_gn_apply(int dtype, const GnParams& p, hipStream_t stream);
+hipError_t launch_gn_stats(int mode, const void* X, float* partial, int B, int HW, int C, Planes pl, hipStream_t stream);
+hipError_t launch_gn_apply(int mode, const GnParams& p, Planes pl, hipStream_t stream);
 // stem: Y[B,Ho,Wo,C] = maxpool3x3s2_SAME( relu(gn(X[B,H,W,C])) )
-hipError_t launch_gn_relu_maxpool(int dtype, const void* X, void* Y, const float* gamma, const float* beta,
-                                  const float* partial, int B, int H, int W, int C, float eps, hipStream_t stream);
+hipError_t launch_gn_relu_maxpool(int mode, const void* X, void* Y, const float* gamma, const float* beta,
+                                  const float* partial, int B, int H, int W, int C, float eps, Planes pl, hipStream_t stream);
 
 // stem im2col: x NCHW fp32 [B,3,H,W] -> col [B*Ho*Wo, 192] 16-bit, k = (ky*7+kx)*3 + c, TF-SAME pad
-hipError_t launch_im2col_stem(int dtype, const float* x, void* col, int B, int H, int W, hipStream_t stream);
+hipError_t launch_im2col_stem(int mode, const float* x, void* col, int B, int H, int W, Planes pl, hipStream_t stream);
 
 // bilinear x2 align_corners=True on NHWC 16-bit
-hipError_t launch_upsample2x(int dtype, const void* X, void* Y, int B, int H, int W, int C, hipStream_t stream);
+hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream);
 
 // y NCHW fp32 [B,Cout,HW] = act( W[Cout][32] * x[B*HW,32] + b ),  Cout <= 4
-hipError_t launch_head_out(int dtype, const void* X, const float* w, const float* b, float* y, int B, int HW,
-                           int Cout, int relu, hipStream_t stream);
+hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, float* y, int B, int HW,
+                           int Cout, int relu, Planes pl, hipStream_t stream);
 
 // X[b*577] = cls + pos[0]  (fp32 token stream)
 hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, int S, int C, hipStream_t stream);
 
 // out[b][n] = bias[n] + sum_k x[b*x_stride + k] * W[n*ldw + w_off + k]   (x fp32, W 16-bit, out fp32)
-hipError_t launch_readout_cls(int dtype, const float* x, long long x_stride, const void* W, int ldw, int w_off,
-                              const float* bias, float* out, int B, int N, int K, hipStream_t stream);
+hipError_t launch_readout_cls(int mode, const float* x, long long x_stride, const void* W, int ldw, int w_off,
+                              const float* bias, float* out, int B, int N, int K, Planes pl, hipStream_t stream);
+// fp32 -> 16-bit (hi/lo planes in bf16x3 mode), n % 8 == 0
+hipError_t launch_cast_f32(int mode, const float* src, void* dst, size_t n, Planes pl, hipStream_t stream);
 
 // generic 16-bit / fp32 -> fp32 copy for taps
-hipError_t launch_to_f32(int dtype, const void* src, float* dst, size_t n, hipStream_t stream);
+hipError_t launch_to_f32(int mode, const void* src, float* dst, size_t n, Planes pl, hipStream_t stream);
 
 }  // namespace dptx

@@ -9,9 +9,9 @@ namespace dptx {
 // ------------------------------------------------------------------------- stem im2col (7x7 s2)
 // x NCHW fp32 [B,3,H,W] -> col[B*Ho*Wo][192] 16-bit, k = (ky*7+kx)*3 + c (k >= 147 zero).
 // TF-SAME padding (timm StdConv2dSame): pad_total = (Ho-1)*2 + 7 - H, top/left = pad_total/2.
-template <int DT>
+template <int DT, int PL>
 __global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ x, uint16_t* __restrict__ col, int B,
-                                                          int H, int W, int Ho, int Wo, int pt, int pl) {
+                                                          int H, int W, int Ho, int Wo, int pt, int pl, long long plane) {
   const long long total = (long long)B * Ho * Wo * 24;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int j = (int)(i % 24);
@@ -32,21 +32,17 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restric
       }
       f[e] = val;
     }
-    *(uint4*)(col + pix * 192 + j * 8) = pack8<DT>(f);
+    store8f<DT, PL>(col + pix * 192 + j * 8, plane, f);
   }
 }
 
-hipError_t launch_im2col_stem(int dtype, const float* x, void* col, int B, int H, int W, hipStream_t stream) {
+hipError_t launch_im2col_stem(int mode, const float* x, void* col, int B, int H, int W, Planes pl, hipStream_t stream) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int pth = max((Ho - 1) * 2 + 7 - H, 0), ptw = max((Wo - 1) * 2 + 7 - W, 0);
   const long long total = (long long)B * Ho * Wo * 24;
   const int grid = (int)min((total + 255) / 256, (long long)8192);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(im2col_stem_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, x, (uint16_t*)col, B, H, W, Ho, Wo, pth / 2, ptw / 2);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(im2col_stem_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, x, (uint16_t*)col, B, H, W, Ho, Wo, pth / 2, ptw / 2);
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((im2col_stem_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, x, (uint16_t*)col, B,
+                                              H, W, Ho, Wo, pth / 2, ptw / 2, pl.act));
   return hipGetLastError();
 }
 
@@ -54,9 +50,9 @@ hipError_t launch_im2col_stem(int dtype, const float* x, void* col, int B, int H
 // blocks.py:335-337 / dpt_depth.py:93: F.interpolate(scale_factor=2, mode="bilinear",
 // align_corners=True).  Index/lambda arithmetic follows ATen's fp32 formulation:
 // ratio = (in-1)/(out-1); src = ratio*dst; i0 = int(src); i1 = i0 + (i0 < in-1); l1 = src - i0.
-template <int DT>
+template <int DT, int PL>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y, int B, int H,
-                                                         int W, int C) {
+                                                         int W, int C, long long plane) {
   const int Ho = 2 * H, Wo = 2 * W, cvec = C >> 3;
   const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
   const float rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -74,41 +70,36 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restr
     const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
     const uint16_t* img = X + (long long)b * H * W * C + v * 8;
     float a[8], bb[8], c[8], d[8], o[8];
-    unpack8<DT>(*(const uint4*)(img + ((long long)y0 * W + x0) * C), a);
-    unpack8<DT>(*(const uint4*)(img + ((long long)y0 * W + x1) * C), bb);
-    unpack8<DT>(*(const uint4*)(img + ((long long)y1 * W + x0) * C), c);
-    unpack8<DT>(*(const uint4*)(img + ((long long)y1 * W + x1) * C), d);
+    load8f<DT, PL>(img + ((long long)y0 * W + x0) * C, plane, a);
+    load8f<DT, PL>(img + ((long long)y0 * W + x1) * C, plane, bb);
+    load8f<DT, PL>(img + ((long long)y1 * W + x0) * C, plane, c);
+    load8f<DT, PL>(img + ((long long)y1 * W + x1) * C, plane, d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
-    *(uint4*)(Y + pix * C + v * 8) = pack8<DT>(o);
+    store8f<DT, PL>(Y + pix * C + v * 8, plane, o);
   }
 }
 
-hipError_t launch_upsample2x(int dtype, const void* X, void* Y, int B, int H, int W, int C, hipStream_t stream) {
+hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream) {
   if (C % 8 != 0) return hipErrorInvalidValue;
   const long long total = (long long)B * 4 * H * W * (C / 8);
   const int grid = (int)min((total + 255) / 256, (long long)16384);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(upsample2x_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, (uint16_t*)Y, B, H, W, C);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(upsample2x_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, (uint16_t*)Y, B, H, W, C);
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((upsample2x_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)X,
+                                              (uint16_t*)Y, B, H, W, C, pl.act));
   return hipGetLastError();
 }
 
 // ----------------------------------------------------------------- head: conv1x1 32->C (+ReLU)
 // dpt_depth.py:96-98.  X [B*HW][32] 16-bit (already ReLU'd) -> y NCHW fp32 [B][C][HW].
-template <int DT>
+template <int DT, int PL>
 __global__ __launch_bounds__(256) void head_out_kernel(const uint16_t* __restrict__ X, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int HW,
-                                                       int Cout, int relu) {
+                                                       int Cout, int relu, long long plane) {
   const long long total = (long long)B * HW;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     float f[32];
-    const uint4* src = (const uint4*)(X + i * 32);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) unpack8<DT>(src[q], f + 8 * q);
+    for (int q = 0; q < 4; ++q) load8f<DT, PL>(X + i * 32 + q * 8, plane, f + 8 * q);
     const long long b = i / HW, p = i - b * HW;
     for (int c = 0; c < Cout; ++c) {
       float acc = bias[c];
@@ -120,16 +111,12 @@ __global__ __launch_bounds__(256) void head_out_kernel(const uint16_t* __restric
   }
 }
 
-hipError_t launch_head_out(int dtype, const void* X, const float* w, const float* b, float* y, int B, int HW, int Cout,
-                           int relu, hipStream_t stream) {
+hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, float* y, int B, int HW, int Cout,
+                           int relu, Planes pl, hipStream_t stream) {
   const long long total = (long long)B * HW;
   const int grid = (int)min((total + 255) / 256, (long long)16384);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(head_out_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, w, b, y, B, HW, Cout, relu);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(head_out_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, w, b, y, B, HW, Cout, relu);
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((head_out_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, w, b,
+                                              y, B, HW, Cout, relu, pl.act));
   return hipGetLastError();
 }
 
@@ -151,11 +138,11 @@ hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, 
 // cat(tok, cls) @ W^T = tok @ W[:, :768]^T + cls @ W[:, 768:]^T : the second term is one
 // vector per image, computed here and consumed as a per-image bias by the token GEMM.
 // One wave per (image, output feature).
-template <int DT>
+template <int DT, int PL>
 __global__ __launch_bounds__(256) void readout_cls_kernel(const float* __restrict__ x, long long x_stride,
                                                           const uint16_t* __restrict__ W, int ldw, int w_off,
                                                           const float* __restrict__ bias, float* __restrict__ out, int B, int N,
-                                                          int K) {
+                                                          int K, long long wplane) {
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (idx >= B * N) return;
@@ -166,40 +153,58 @@ __global__ __launch_bounds__(256) void readout_cls_kernel(const float* __restric
   for (int k = lane * 4; k < K; k += 256) {
     const float4 xv = *(const float4*)(xr + k);
     const uint2 wv = *(const uint2*)(wr + k);
-    acc += xv.x * T16<DT>::tof((uint16_t)(wv.x & 0xffffu)) + xv.y * T16<DT>::tof((uint16_t)(wv.x >> 16)) +
-           xv.z * T16<DT>::tof((uint16_t)(wv.y & 0xffffu)) + xv.w * T16<DT>::tof((uint16_t)(wv.y >> 16));
+    float w0 = T16<DT>::tof((uint16_t)(wv.x & 0xffffu)), w1 = T16<DT>::tof((uint16_t)(wv.x >> 16));
+    float w2 = T16<DT>::tof((uint16_t)(wv.y & 0xffffu)), w3 = T16<DT>::tof((uint16_t)(wv.y >> 16));
+    if (PL == 2) {
+      const uint2 wl = *(const uint2*)(wr + wplane + k);
+      w0 += T16<DT>::tof((uint16_t)(wl.x & 0xffffu)); w1 += T16<DT>::tof((uint16_t)(wl.x >> 16));
+      w2 += T16<DT>::tof((uint16_t)(wl.y & 0xffffu)); w3 += T16<DT>::tof((uint16_t)(wl.y >> 16));
+    }
+    acc += xv.x * w0 + xv.y * w1 + xv.z * w2 + xv.w * w3;
   }
   acc = wave_sum(acc);
   if (lane == 0) out[idx] = acc + (bias ? bias[n] : 0.f);
 }
 
-hipError_t launch_readout_cls(int dtype, const float* x, long long x_stride, const void* W, int ldw, int w_off,
-                              const float* bias, float* out, int B, int N, int K, hipStream_t stream) {
+hipError_t launch_readout_cls(int mode, const float* x, long long x_stride, const void* W, int ldw, int w_off,
+                              const float* bias, float* out, int B, int N, int K, Planes pl, hipStream_t stream) {
   if (K % 4 != 0 || w_off % 4 != 0 || ldw % 4 != 0) return hipErrorInvalidValue;
   dim3 grid((B * N + 3) / 4);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(readout_cls_kernel<DT_BF16>, grid, dim3(256), 0, stream, x, x_stride, (const uint16_t*)W, ldw, w_off, bias, out, B, N, K);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(readout_cls_kernel<DT_FP16>, grid, dim3(256), 0, stream, x, x_stride, (const uint16_t*)W, ldw, w_off, bias, out, B, N, K);
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((readout_cls_kernel<DT, PL>), grid, dim3(256), 0, stream, x, x_stride,
+                                              (const uint16_t*)W, ldw, w_off, bias, out, B, N, K, pl.w));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------- fp32 -> 16-bit (planes)
+// The ProjectReadout GEMM consumes the fp32 token stream: it is rounded (or split into hi/lo
+// planes) once here so that the GEMM can use the direct-to-LDS path.
+template <int DT, int PL>
+__global__ __launch_bounds__(256) void cast_f32_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n8,
+                                                       long long plane) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const float4 a = *(const float4*)(src + i * 8), b = *(const float4*)(src + i * 8 + 4);
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    store8f<DT, PL>(dst + i * 8, plane, f);
+  }
+}
+hipError_t launch_cast_f32(int mode, const float* src, void* dst, size_t n, Planes pl, hipStream_t stream) {
+  if (n % 8 != 0) return hipErrorInvalidValue;
+  const int grid = (int)min((n / 8 + 255) / 256, (size_t)8192);
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((cast_f32_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, src, (uint16_t*)dst, n / 8,
+                                              pl.act));
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------ tap export
-template <int DT>
-__global__ void to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+template <int DT, int PL>
+__global__ void to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n, long long plane) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    dst[i] = T16<DT>::tof(src[i]);
+    dst[i] = T16<DT>::tof(src[i]) + (PL == 2 ? T16<DT>::tof(src[i + plane]) : 0.f);
 }
-hipError_t launch_to_f32(int dtype, const void* src, float* dst, size_t n, hipStream_t stream) {
+hipError_t launch_to_f32(int mode, const void* src, float* dst, size_t n, Planes pl, hipStream_t stream) {
   const int grid = (int)min((n + 255) / 256, (size_t)8192);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(to_f32_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)src, dst, n);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(to_f32_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)src, dst, n);
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((to_f32_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)src, dst, n,
+                                              pl.act));
   return hipGetLastError();
 }
 

@@ -9,10 +9,10 @@ namespace dptx {
 // ------------------------------------------------------------------------------ LayerNorm
 // x fp32 [M][C] (the fp32 residual stream) -> y 16-bit [M][C].  One wave per row; C = 768:
 // each lane owns 3 float4.  Two-pass (mean, then centred variance) in registers.
-template <int DT, int VPL>
+template <int DT, int PL, int VPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, uint16_t* __restrict__ y,
-                                                        int M, int C, float eps) {
+                                                        int M, int C, float eps, long long plane) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -37,23 +37,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int j = 0; j < VPL; ++j) {
     const int c0 = (j * 64 + lane) * 4;
     const float4 g = *(const float4*)(gamma + c0), bb = *(const float4*)(beta + c0);
+    const float o0 = (v[j].x - mean) * rstd * g.x + bb.x, o1 = (v[j].y - mean) * rstd * g.y + bb.y;
+    const float o2 = (v[j].z - mean) * rstd * g.z + bb.z, o3 = (v[j].w - mean) * rstd * g.w + bb.w;
     uint2 w;
-    w.x = T16<DT>::pack2((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y);
-    w.y = T16<DT>::pack2((v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w);
+    w.x = T16<DT>::pack2(o0, o1);
+    w.y = T16<DT>::pack2(o2, o3);
     *(uint2*)(yr + c0) = w;
+    if (PL == 2) {
+      uint2 l;
+      l.x = T16<DT>::pack2(o0 - T16<DT>::tof((uint16_t)(w.x & 0xffffu)), o1 - T16<DT>::tof((uint16_t)(w.x >> 16)));
+      l.y = T16<DT>::pack2(o2 - T16<DT>::tof((uint16_t)(w.y & 0xffffu)), o3 - T16<DT>::tof((uint16_t)(w.y >> 16)));
+      *(uint2*)(yr + plane + c0) = l;
+    }
   }
 }
 
-hipError_t launch_layernorm(int dtype, const float* x, const float* gamma, const float* beta, void* y, int M, int C,
-                            float eps, hipStream_t stream) {
+hipError_t launch_layernorm(int mode, const float* x, const float* gamma, const float* beta, void* y, int M, int C,
+                            float eps, Planes pl, hipStream_t stream) {
   if (C != 768) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL((layernorm_kernel<DT_BF16, 3>), grid, dim3(256), 0, stream, x, gamma, beta, (uint16_t*)y, M, C, eps);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL((layernorm_kernel<DT_FP16, 3>), grid, dim3(256), 0, stream, x, gamma, beta, (uint16_t*)y, M, C, eps);
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((layernorm_kernel<DT, PL, 3>), grid, dim3(256), 0, stream, x, gamma, beta,
+                                              (uint16_t*)y, M, C, eps, pl.act));
   return hipGetLastError();
 }
 
@@ -70,9 +74,9 @@ int gn_chunks(int HW) {
 }
 static inline int gn_pix(int HW) { return HW <= 2304 ? 64 : 256; }
 
-template <int DT>
+template <int DT, int PL>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X, float* __restrict__ partial,
-                                                       int HW, int C, int pix) {
+                                                       int HW, int C, int pix, long long plane) {
   __shared__ float red[256 * 8];  // per thread: up to 4 (sum, sumsq) pairs
   const int tid = threadIdx.x;
   const int cvec = C >> 3;            // 16-B vectors per pixel (8..128)
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
   const uint16_t* base = X + ((long long)b * HW) * C + v * 8;
   for (int p = pbeg + p0; p < pend; p += pstep) {
     float f[8];
-    unpack8<DT>(*(const uint4*)(base + (long long)p * C), f);
+    load8f<DT, PL>(base + (long long)p * C, plane, f);
     if (spv == 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[0] += f[e]; q[0] += f[e] * f[e]; }
@@ -120,15 +124,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
   }
 }
 
-hipError_t launch_gn_stats(int dtype, const void* X, float* partial, int B, int HW, int C, hipStream_t stream) {
+hipError_t launch_gn_stats(int mode, const void* X, float* partial, int B, int HW, int C, Planes pl, hipStream_t stream) {
   if (C % 64 != 0 || C > 1024 || (256 % (C / 8)) != 0) return hipErrorInvalidValue;
   dim3 grid(gn_chunks(HW), B);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(gn_stats_kernel<DT_BF16>, grid, dim3(256), 0, stream, (const uint16_t*)X, partial, HW, C, gn_pix(HW));
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(gn_stats_kernel<DT_FP16>, grid, dim3(256), 0, stream, (const uint16_t*)X, partial, HW, C, gn_pix(HW));
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_stats_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X, partial,
+                                              HW, C, gn_pix(HW), pl.act));
   return hipGetLastError();
 }
 
@@ -159,8 +159,8 @@ __device__ __forceinline__ void gn_affine_to_lds(const float* __restrict__ parti
   __syncthreads();
 }
 
-template <int DT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix, int nchunks) {
+template <int DT, int PL>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix, int nchunks, long long plane) {
   __shared__ float sa[1024], sd[1024], ra[1024], rd[1024], smr[64];
   const int b = blockIdx.y;
   gn_affine_to_lds(p.partial, nchunks, b, p.gamma, p.beta, p.C, p.HW, p.eps, sa, sd, smr);
@@ -178,12 +178,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix
     const int pi = i / cvec, v = i - pi * cvec;
     const long long off = (long long)(pbeg + pi) * p.C + v * 8;
     float f[8];
-    unpack8<DT>(*(const uint4*)(X + off), f);
+    load8f<DT, PL>(X + off, plane, f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] = f[e] * sa[v * 8 + e] + sd[v * 8 + e];
     if (R != nullptr) {
       float r[8];
-      unpack8<DT>(*(const uint4*)(R + off), r);
+      load8f<DT, PL>(R + off, plane, r);
       if (r_gn) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = r[e] * ra[v * 8 + e] + rd[v * 8 + e];
@@ -195,30 +195,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
     }
-    *(uint4*)(Y + off) = pack8<DT>(f);
+    store8f<DT, PL>(Y + off, plane, f);
   }
 }
 
-hipError_t launch_gn_apply(int dtype, const GnParams& p, hipStream_t stream) {
+hipError_t launch_gn_apply(int mode, const GnParams& p, Planes pl, hipStream_t stream) {
   if (p.C % 64 != 0 || p.C > 1024) return hipErrorInvalidValue;
   const int nch = gn_chunks(p.HW);
   dim3 grid(nch, p.B);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<DT_BF16>, grid, dim3(256), 0, stream, p, gn_pix(p.HW), nch);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(gn_apply_kernel<DT_FP16>, grid, dim3(256), 0, stream, p, gn_pix(p.HW), nch);
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_apply_kernel<DT, PL>), grid, dim3(256), 0, stream, p, gn_pix(p.HW), nch, pl.act));
   return hipGetLastError();
 }
 
 // stem: GN + ReLU + MaxPool2dSame(3, stride 2): pad (0,1) bottom/right; padded taps are skipped
 // (equivalent to timm's -inf padding).  One thread = one output pixel x 8 channels.
-template <int DT>
+template <int DT, int PL>
 __global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ partial, int nchunks, int H, int W,
-                                                              int C, float eps) {
+                                                              int C, float eps, long long plane) {
   __shared__ float sa[1024], sd[1024], smr[64];
   const int b = blockIdx.y;
   gn_affine_to_lds(partial, nchunks, b, gamma, beta, C, H * W, eps, sa, sd, smr);
@@ -242,29 +237,23 @@ __global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const uint16_t* __
         const int ix = 2 * ox + dx;
         if (ix >= W) continue;
         float f[8];
-        unpack8<DT>(*(const uint4*)(Xi + ((long long)iy * W + ix) * C + v * 8), f);
+        load8f<DT, PL>(Xi + ((long long)iy * W + ix) * C + v * 8, plane, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], f[e] * sa[v * 8 + e] + sd[v * 8 + e]);
       }
     }
-    *(uint4*)(Yo + (long long)po * C + v * 8) = pack8<DT>(m);
+    store8f<DT, PL>(Yo + (long long)po * C + v * 8, plane, m);
   }
 }
 
-hipError_t launch_gn_relu_maxpool(int dtype, const void* X, void* Y, const float* gamma, const float* beta,
-                                  const float* partial, int B, int H, int W, int C, float eps, hipStream_t stream) {
+hipError_t launch_gn_relu_maxpool(int mode, const void* X, void* Y, const float* gamma, const float* beta,
+                                  const float* partial, int B, int H, int W, int C, float eps, Planes pl, hipStream_t stream) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int total = Ho * Wo * (C / 8);
   dim3 grid(min((total + 255) / 256, 1024), B);
   const int nch = gn_chunks(H * W);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(gn_relu_maxpool_kernel<DT_BF16>, grid, dim3(256), 0, stream, (const uint16_t*)X, (uint16_t*)Y, gamma,
-                       beta, partial, nch, H, W, C, eps);
-  else if (dtype == DT_FP16)
-    hipLaunchKernelGGL(gn_relu_maxpool_kernel<DT_FP16>, grid, dim3(256), 0, stream, (const uint16_t*)X, (uint16_t*)Y, gamma,
-                       beta, partial, nch, H, W, C, eps);
-  else
-    return hipErrorInvalidValue;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_relu_maxpool_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X,
+                                              (uint16_t*)Y, gamma, beta, partial, nch, H, W, C, eps, pl.act));
   return hipGetLastError();
 }
 

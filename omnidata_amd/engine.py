@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdptx.so")
 
-DTYPES = {"bf16": 0, "fp16": 1}
+DTYPES = {"bf16": 0, "fp16": 1, "bf16x3": 2}
 ERRORS = {0: "ok", -1: "invalid argument / call order", -2: "state_dict key error", -3: "HIP error",
           -4: "no device", -5: "allocation failed"}
 
@@ -45,6 +45,7 @@ ABI = [
     ("dptx_profile_dump", C.c_int, [_vp, C.c_char_p]),
     ("dptx_last_error", C.c_char_p, [_vp]),
     ("dptx_version", C.c_char_p, []),
+    ("dptx_op_set_planes", C.c_int, [C.c_int64, C.c_int64]),
     ("dptx_op_gemm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("dptx_op_conv", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [_vp]),
     ("dptx_op_attention", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -33,8 +33,8 @@ class BaseModel(nn.Module):
 class DPTDepthModel(BaseModel):
     """Drop-in for ``DPTDepthModel(backbone='vitb_rn50_384', num_channels={1,3})``.
 
-    Extra keyword arguments (engine side): ``dtype`` in {'bf16','fp16'} -- MFMA operand /
-    activation storage type; ``max_batch`` -- arena size (larger batches are chunked).
+    Extra keyword arguments (engine side): ``dtype`` in {'bf16','fp16','bf16x3'} -- MFMA operand /
+    activation storage type ('bf16x3' = hi/lo bf16 planes, 3 MFMAs per product, meets 1e-3 abs); ``max_batch`` -- arena size (larger batches are chunked).
     """
 
     def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,

@@ -43,3 +43,46 @@ def op_conv(dtype, X, Wt, bias, R, stride, pad_t, pad_l, Ho, Wo, a_relu=0, act=0
                           pad_t, pad_l, Ho, Wo, a_relu, act, stream())
     assert rc == 0, rc
     return Y
+
+
+class PlaneArena:
+    """bf16x3 test storage: every tensor is a (hi, lo) pair of bf16 planes a fixed distance apart,
+    exactly like the engine's arena/blob halves."""
+
+    def __init__(self, total_elems, device="cuda:0"):
+        total_elems = (total_elems + 4095) // 4096 * 4096
+        self.buf = torch.zeros(2, total_elems, dtype=torch.bfloat16, device=device)
+        self.total, self.off = total_elems, 0
+        load_library().dptx_op_set_planes(total_elems, total_elems)
+
+    def _take(self, n):
+        o = self.off
+        self.off += (n + 127) // 128 * 128
+        assert self.off <= self.total
+        return o
+
+    def put(self, t):
+        t = t.float().to(self.buf.device)
+        o = self._take(t.numel())
+        hi = t.to(torch.bfloat16)
+        self.buf[0, o:o + t.numel()] = hi.flatten()
+        self.buf[1, o:o + t.numel()] = (t - hi.float()).to(torch.bfloat16).flatten()
+        return self.buf[0, o:o + t.numel()].view(t.shape)
+
+    def empty(self, *shape):
+        n = 1
+        for s in shape:
+            n *= s
+        o = self._take(n)
+        return self.buf[0, o:o + n].view(*shape)
+
+    def value(self, hi_view):
+        """fp64 value hi + lo of a tensor handed out by put()/empty()."""
+        o = hi_view.data_ptr() - self.buf.data_ptr()
+        assert o % 2 == 0
+        o //= 2
+        n = hi_view.numel()
+        return (self.buf[0, o:o + n].double() + self.buf[1, o:o + n].double()).view(hi_view.shape)
+
+    def release(self):
+        load_library().dptx_op_set_planes(0, 0)

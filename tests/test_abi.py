@@ -145,3 +145,27 @@ def test_fp16_conversion_edge_cases(built_lib):
     got = torch.from_numpy(blob[o:o + b].copy()).view(torch.float16)
     ref = w.flatten().to(torch.float16)
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+def test_bf16x3_packing_has_hi_and_lo_planes(built_lib):
+    """bf16x3 blob = [hi blob | lo blob]: hi is exactly the bf16 blob, lo = bf16(w - hi)."""
+    from omnidata_amd.engine import Engine
+    sd = random_state_dict(4, 3)
+    e1 = Engine(num_channels=3, max_batch=1, dtype="bf16", device_id=None)
+    e1.load_state_dict(sd)
+    e3 = Engine(num_channels=3, max_batch=1, dtype="bf16x3", device_id=None)
+    e3.load_state_dict(sd)
+    b1, b3 = e1.export_packed_host(), e3.export_packed_host()
+    assert b3.size == 2 * b1.size == e3.packed_bytes
+    assert np.array_equal(b3[: b1.size], b1)
+    offs, _ = _blob_offsets(state_dict_spec(3).items())
+    k = "pretrained.model.blocks.2.mlp.fc2.weight"
+    o, b = offs[k]
+    lo = torch.from_numpy(b3[b1.size + o: b1.size + o + b].copy()).view(torch.bfloat16).float()
+    w = sd[k].flatten()
+    hi = w.to(torch.bfloat16).float()
+    assert torch.equal(lo, (w - hi).to(torch.bfloat16).float())
+    assert (w - hi - lo).abs().max() <= 2.0 ** -16 * w.abs().max()   # 16 significand bits
+    # fp32 vectors live only in the hi half
+    o, b = offs["pretrained.model.pos_embed"]
+    assert not b3[b1.size + o: b1.size + o + b].any()
