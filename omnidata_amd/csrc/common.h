@@ -144,16 +144,16 @@ __device__ __forceinline__ void store8f(uint16_t* p, long long plane, const floa
     *(uint4*)(p + plane) = pack8<DT>(l);
   }
 }
-// ReLU of a hi/lo pair: sign(x) == sign(hi), so lo is zeroed wherever hi is negative
+// ReLU of a hi/lo pair: sign(x) == sign(hi), so lo is zeroed wherever hi is negative.
+// Whole-vector form (an element-indexed loop over a vector reference was miscompiled by hipcc
+// 7.2 into "element 0 broadcast to all four dwords").
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void relu8_planes(u32x4_t& hi, u32x4_t& lo) {
-  const s16x2_t z = {0, 0};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const s16x2_t h = __builtin_bit_cast(s16x2_t, hi[i]);
-    const s16x2_t neg = h >> 15;  // 0xFFFF where negative
-    lo[i] = lo[i] & ~__builtin_bit_cast(uint32_t, neg);
-    hi[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(h, z));
-  }
+  const s16x8_t h = __builtin_bit_cast(s16x8_t, hi);
+  const s16x8_t neg = h >> 15;  // 0xFFFF where negative
+  const s16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  lo = __builtin_bit_cast(u32x4_t, (s16x8_t)(__builtin_bit_cast(s16x8_t, lo) & ~neg));
+  hi = __builtin_bit_cast(u32x4_t, __builtin_elementwise_max(h, zero));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {

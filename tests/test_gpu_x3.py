@@ -51,7 +51,7 @@ def test_x3_conv(case):
         bias = torch.randn(Cout, device=DEV) * 0.1
         assert lib.dptx_op_conv(X3, ptr(X), ptr(Wt), ptr(bias), ptr(R), ptr(Y), B, H, H, Cin, Cout, k, stride, pad, pad, Ho, Ho,
                                 a_relu, act, stream()) == 0
-        ref = conv_ref(ar.value(X), ar.value(Wt), bias.double(), stride, pad, pad, Ho, Ho, a_relu)
+        ref = conv_ref(ar.value(X), ar.value(Wt), bias, stride, pad, pad, Ho, Ho, a_relu).double()
         if act == 1:
             ref = F.relu(ref)
         ref = ref + ar.value(R)
@@ -110,9 +110,15 @@ def test_x3_end_to_end_meets_1e3(task, C, seed, B):
     model = DPTDepthModel(num_channels=C, dtype="bf16x3", max_batch=B)
     model.load_state_dict(sd)
     model.to(DEV)
+    eng = model._get_engine(torch.device(DEV))
+    eng.enable_taps(True)
     y = model(x.to(DEV)).cpu()
     d = (y - ref).abs()
     print(f"\n[{task} seed={seed} B={B} bf16x3] max|d|={d.max():.3e} rms={d.pow(2).mean().sqrt():.3e}")
+    _, _, _, otaps = oracle_case(task, C, seed, B)
+    for n in ["stem", "s0", "s1", "s2", "tok0", "blk0", "blk8", "blk11", "l3", "l4", "l1_rn", "l4_rn", "p4", "p3", "p2", "p1", "h0", "h1"]:
+        got, want = eng.tap(n), otaps[n]
+        print(f"    tap {n:6s} rms-rel err {((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item():.3e}")
     assert y.shape == ref.shape and torch.isfinite(y).all()
     assert d.max().item() < 1e-3
     if task == "normal":
