@@ -73,7 +73,7 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
   }
 }
 
-template <int DT, int BM, int BN, int TM, int TN, int PL = 1>
+template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                          int tid, f32x16_t (&acc)[TM][TN]) {
   constexpr int CT_PITCH = BN + 4;  // floats
@@ -91,7 +91,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   __syncthreads();
 
   constexpr int NCH = BN / 8;     // 8-column chunks per tile row
-  constexpr int RPP = 256 / NCH;  // tile rows per pass
+  constexpr int RPP = NT / NCH;   // tile rows per pass
   const int cn = tid % NCH;
   const int rr = tid / NCH;
   const int n = n0 + cn * 8;
@@ -191,10 +191,20 @@ __global__ __launch_bounds__(256, PL == 2 ? 1 : 2) void gemm_glds_kernel(const G
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int lr = lane & 31, lh = lane >> 5;
 
-  const int tiles_n = p.N / BN;
-  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int n0 = (wg % tiles_n) * BN;
-  const int m0 = (wg / tiles_n) * BM;
+  // block -> tile: XCD x = blockIdx % 8 (observed dispatch placement; only speed depends on it) owns the
+  // (x / xcd_n)-th m-slice and (x % xcd_n)-th n-slice of the tile grid; inside a slice n runs fastest so
+  // consecutive blocks of one XCD share their A rows.
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
+    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
+    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
+    if (mt >= tiles_m || l >= tm_per * tn_per) return;
+    m0 = mt * BM;
+    n0 = nt * BN;
+  }
 
   // loader: thread (r0 = tid>>3, kc = tid&7) owns LDS chunk kc of rows r0 + 32*i and fetches the
   // SOURCE chunk kc ^ ((r0>>1)&7)   ((row>>1)&7 is the same for every pass: 32*i leaves bits 1..3)
@@ -301,10 +311,20 @@ __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int lr = lane & 31, lh = lane >> 5;
 
-  const int tiles_n = p.N / BN;
-  const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int n0 = (wg % tiles_n) * BN;
-  const int m0 = (wg / tiles_n) * BM;
+  // block -> tile: XCD x = blockIdx % 8 (observed dispatch placement; only speed depends on it) owns the
+  // (x / xcd_n)-th m-slice and (x % xcd_n)-th n-slice of the tile grid; inside a slice n runs fastest so
+  // consecutive blocks of one XCD share their A rows.
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
+    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
+    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
+    if (mt >= tiles_m || l >= tm_per * tn_per) return;
+    m0 = mt * BM;
+    n0 = nt * BN;
+  }
 
   const int kc = tid & 7, r0 = tid >> 3;
   int a_iy0[A_PASSES], a_ix0[A_PASSES];
@@ -426,7 +446,9 @@ static void set_smem_attr(K k, size_t smem) {
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
-static int gemm_variant() {  // DPTX_GEMM=reg forces the register-staged kernel (A/B experiments)
+// A/B experiments: DPTX_GEMM=reg forces the register-staged kernel; DPTX_XCD=0 disables the 2-D XCD
+// partition of the tile grid.
+static int gemm_variant() {
   static int v = -1;
   if (v < 0) {
     const char* s = getenv("DPTX_GEMM");
@@ -434,24 +456,55 @@ static int gemm_variant() {  // DPTX_GEMM=reg forces the register-staged kernel 
   }
   return v;
 }
+static int xcd_partition_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* s = getenv("DPTX_XCD");
+    v = (s && s[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
+// Chooses the XCD grid (xm x xn, xm*xn = 8) for a tile grid: XCD (xi, xj) owns the m-tiles of slice xi
+// and the n-tiles of slice xj, so per XCD only A/xm and W/xn are touched.  Objective: HBM/MALL-side
+// traffic xn*A_bytes + xm*W_bytes, subject to the XCD's W slice fitting comfortably in its 4 MB L2
+// (otherwise W is re-fetched for every m-tile) and xn dividing the n-tile count.
+static void choose_xcd_grid(const GemmParams& p, int tiles_m, int tiles_n, int& xm, int& xn) {
+  xm = 8; xn = 1;
+  if (!xcd_partition_enabled()) return;
+  const double a_bytes = (double)p.M * p.K * 2.0, w_bytes = (double)p.N * p.K * 2.0;
+  double best = -1.0;
+  const int cand[4] = {1, 2, 4, 8};
+  for (int c = 0; c < 4; ++c) {
+    const int n = cand[c], m = 8 / n;
+    if (tiles_n % n != 0 || tiles_m < m) continue;
+    const double w_slice = w_bytes / n;
+    double cost = n * a_bytes + m * w_bytes;
+    if (w_slice > 2.0e6) cost += (double)tiles_m / m * w_slice * 8.0;  // L2 thrash: W slice re-read per m-tile
+    if (best < 0.0 || cost < best) { best = cost; xm = m; xn = n; }
+  }
+}
 
 template <int DT, int PL, int BM, int BN, int WM_, int WN_>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
-  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+  GemmParams q = p;
+  choose_xcd_grid(p, tiles_m, tiles_n, q.xcd_m, q.xcd_n);
+  const int tiles = 8 * ((tiles_m + q.xcd_m - 1) / q.xcd_m) * (tiles_n / q.xcd_n);
   constexpr size_t smem = gemm_smem_bytes<BM, BN, PL>();
   const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31);
   if (PL == 2 && !glds_ok) return hipErrorInvalidValue;  // the 3-pass mode exists only on the direct-to-LDS path
-  if (glds_ok && (PL == 2 || gemm_variant() == 0)) {
+  if (glds_ok && (PL == 2 || gemm_variant() != 1)) {
     if (p.a_relu) {
       auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL>;
       static bool done = false;
       if (!done) { set_smem_attr(k, smem); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, q);
     } else {
       auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
       static bool done = false;
       if (!done) { set_smem_attr(k, smem); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, p);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, q);
     }
   } else if constexpr (PL == 1) {
     constexpr size_t smem1 = gemm_smem_bytes<BM, BN, 1>();
@@ -459,12 +512,12 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, true>;
       static bool done = false;
       if (!done) { set_smem_attr(k, smem1); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, p);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, q);
     } else {
       auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, false>;
       static bool done = false;
       if (!done) { set_smem_attr(k, smem1); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, p);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, q);
     }
   }
   return hipGetLastError();

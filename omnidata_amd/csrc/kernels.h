@@ -35,6 +35,7 @@ struct GemmParams {
   int a_fp32;        // A elements are fp32 (converted while staging)
   int c_fp32, r1_fp32, r2_fp32;
   Planes planes;  // hi->lo plane distances (bf16x3 mode only)
+  int xcd_m, xcd_n;  // XCD grid of the tile partition (filled in by launch_gemm)
 };
 
 // Fills the "plain dense row-major" defaults for A [M,K] (lda = K) and C [M,N].

@@ -74,6 +74,9 @@ def conv_ref(X, Wt, bias, stride, pad_t, pad_l, Ho, Wo, a_relu):
     (2, 96, 64, 64, 3, 1, 1, 96, 0, 0, False),     # stage0 conv2 (N=64)
     (1, 40, 128, 32, 3, 1, 1, 40, 0, 1, False),    # head conv 128->32 (+ReLU), N=32 tile
     (5, 12, 768, 256, 3, 1, 1, 12, 0, 0, False),   # layer4_rn (small map, K=6912)
+    (8, 96, 256, 256, 3, 1, 1, 96, 1, 1, False),   # big-M RCU conv1: 8-wave 3-stage kernel, pre-ReLU
+    (8, 96, 256, 128, 3, 1, 1, 96, 0, 0, True),    # big-M, N=128, residual: 8-wave 3-stage kernel
+    (9, 48, 512, 256, 3, 1, 1, 48, 0, 0, False),   # layer2_rn at batch 9 (M not a multiple of 256)
 ])
 def test_conv_implicit_gemm(dtype, case):
     B, H, Cin, Cout, k, stride, pad, Ho, a_relu, act, res = case

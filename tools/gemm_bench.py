@@ -23,7 +23,15 @@ CONV = [("rcu@96", 96, 256, 256, 3, 1, 1, 96), ("rcu@48", 48, 256, 256, 3, 1, 1,
         ("s1.b0.c2(s2)", 96, 128, 128, 3, 2, 0, 48), ("pp4.conv2", 24, 768, 768, 3, 2, 1, 12)]
 
 
-def timeit(fn, iters=10):
+ITERS = [10]
+
+
+def timeit(fn, iters=None):
+    iters = iters or ITERS[0]
+    return _timeit(fn, iters)
+
+
+def _timeit(fn, iters):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -39,7 +47,11 @@ def timeit(fn, iters=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default=None, help="comma separated shape names")
+    ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
+    only = set(args.only.split(",")) if args.only else None
+    ITERS[0] = args.iters
     build()
     lib = load_library()
     dt, tdt = DTYPES[args.dtype], (torch.bfloat16 if args.dtype == "bf16" else torch.float16)
@@ -47,6 +59,8 @@ def main():
     print(f"variant={os.environ.get('DPTX_GEMM', 'glds')} dtype={args.dtype}")
     tot_ms, tot_flop = 0.0, 0.0
     for name, M, N, K in DENSE:
+        if only and name not in only:
+            continue
         A = torch.randn(M, K, device="cuda").to(tdt)
         W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(tdt)
         C = torch.empty(M, N, device="cuda", dtype=tdt)
@@ -56,6 +70,8 @@ def main():
         print(f"{name:14s} M={M:8d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s")
         tot_ms += ms; tot_flop += fl
     for name, H, Cin, Cout, k, s, pad, Ho in CONV:
+        if only and name not in only:
+            continue
         X = torch.randn(B, H, H, Cin, device="cuda").to(tdt)
         Wt = (torch.randn(Cout, k, k, Cin, device="cuda") * (k * k * Cin) ** -0.5).to(tdt)
         Y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=tdt)
