@@ -141,18 +141,22 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f((m_run - m_new) * cexp);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);  // raw v_exp_f32: args are <= 0
+      const bool grew = m_new > m_run;
       m_run = m_new;
+      const float mc = m_new * cexp;
       float pv[16];
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pv[r] = exp2f((s[r] - m_new) * cexp);
+        pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], cexp, -mc));
         ps += pv[r];
       }
       l_run = l_run * alpha + ps;  // per-half partial sum; halves are added at the end
+      if (__any(grew)) {           // wave-uniform: once the running max has settled the rescale is skipped
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      }
       uint4 pf[2], pl2[2];
       pf[0] = pack8<DT>(pv);
       pf[1] = pack8<DT>(pv + 8);

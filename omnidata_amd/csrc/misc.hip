@@ -12,36 +12,33 @@ namespace dptx {
 template <int DT, int PL>
 __global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ x, uint16_t* __restrict__ col, int B,
                                                           int H, int W, int Ho, int Wo, int pt, int pl, long long plane) {
-  const long long total = (long long)B * Ho * Wo * 24;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int j = (int)(i % 24);
-    const long long pix = i / 24;
-    const int ox = (int)(pix % Wo);
-    const int oy = (int)((pix / Wo) % Ho);
-    const int b = (int)(pix / ((long long)Wo * Ho));
-    float f[8];
+  // grid (ceil(Wo*24/256), B*Ho): blockIdx.y = (b, oy); thread = (ox, j) with j the 8-wide k chunk
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wo * 24) return;
+  const int ox = idx / 24, j = idx - ox * 24;
+  const int b = blockIdx.y / Ho, oy = blockIdx.y - b * Ho;
+  float f[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = j * 8 + e;
-      float val = 0.f;
-      if (k < 147) {
-        const int tap = k / 3, c = k - tap * 3;
-        const int ky = tap / 7, kx = tap - ky * 7;
-        const int iy = 2 * oy + ky - pt, ix = 2 * ox + kx - pl;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) val = x[(((long long)b * 3 + c) * H + iy) * W + ix];
-      }
-      f[e] = val;
+  for (int e = 0; e < 8; ++e) {
+    const int k = j * 8 + e;
+    float val = 0.f;
+    if (k < 147) {
+      const int tap = k / 3, c = k - tap * 3;
+      const int ky = tap / 7, kx = tap - ky * 7;
+      const int iy = 2 * oy + ky - pt, ix = 2 * ox + kx - pl;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) val = x[((b * 3 + c) * H + iy) * W + ix];
     }
-    store8f<DT, PL>(col + pix * 192 + j * 8, plane, f);
+    f[e] = val;
   }
+  store8f<DT, PL>(col + ((long long)blockIdx.y * Wo + ox) * 192 + j * 8, plane, f);
 }
 
 hipError_t launch_im2col_stem(int mode, const float* x, void* col, int B, int H, int W, Planes pl, hipStream_t stream) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int pth = max((Ho - 1) * 2 + 7 - H, 0), ptw = max((Wo - 1) * 2 + 7 - W, 0);
-  const long long total = (long long)B * Ho * Wo * 24;
-  const int grid = (int)min((total + 255) / 256, (long long)8192);
-  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((im2col_stem_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, x, (uint16_t*)col, B,
+  if ((long long)B * 3 * H * W >= (1ll << 31)) return hipErrorInvalidValue;
+  dim3 grid((Wo * 24 + 255) / 256, B * Ho);
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((im2col_stem_kernel<DT, PL>), grid, dim3(256), 0, stream, x, (uint16_t*)col, B,
                                               H, W, Ho, Wo, pth / 2, ptw / 2, pl.act));
   return hipGetLastError();
 }
@@ -50,42 +47,43 @@ hipError_t launch_im2col_stem(int mode, const float* x, void* col, int B, int H,
 // blocks.py:335-337 / dpt_depth.py:93: F.interpolate(scale_factor=2, mode="bilinear",
 // align_corners=True).  Index/lambda arithmetic follows ATen's fp32 formulation:
 // ratio = (in-1)/(out-1); src = ratio*dst; i0 = int(src); i1 = i0 + (i0 < in-1); l1 = src - i0.
+// grid (ceil(Wo*C/8 / 256), B*Ho): the output row (b, oy) comes from blockIdx.y (one scalar division per
+// block), a thread owns 8 channels of one output pixel; C/8 is a power of two on every call site, so the
+// per-thread index math is shifts and masks.
 template <int DT, int PL>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y, int B, int H,
-                                                         int W, int C, long long plane) {
+                                                         int W, int C, int cshift, long long plane) {
   const int Ho = 2 * H, Wo = 2 * W, cvec = C >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wo * cvec) return;
+  const int v = idx & (cvec - 1), ox = idx >> cshift;
+  const int b = blockIdx.y / Ho, oy = blockIdx.y - b * Ho;
   const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
   const float rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-  const long long total = (long long)B * Ho * Wo * cvec;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int v = (int)(i % cvec);
-    const long long pix = i / cvec;
-    const int ox = (int)(pix % Wo);
-    const int oy = (int)((pix / Wo) % Ho);
-    const int b = (int)(pix / ((long long)Wo * Ho));
-    const float sy = ry * (float)oy, sx = rx * (float)ox;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
-    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-    const uint16_t* img = X + (long long)b * H * W * C + v * 8;
-    float a[8], bb[8], c[8], d[8], o[8];
-    load8f<DT, PL>(img + ((long long)y0 * W + x0) * C, plane, a);
-    load8f<DT, PL>(img + ((long long)y0 * W + x1) * C, plane, bb);
-    load8f<DT, PL>(img + ((long long)y1 * W + x0) * C, plane, c);
-    load8f<DT, PL>(img + ((long long)y1 * W + x1) * C, plane, d);
+  const float sy = ry * (float)oy, sx = rx * (float)ox;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+  const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const uint16_t* img = X + (long long)b * H * W * C + v * 8;
+  float a[8], bb[8], c[8], d[8], o[8];
+  load8f<DT, PL>(img + (y0 * W + x0) * C, plane, a);
+  load8f<DT, PL>(img + (y0 * W + x1) * C, plane, bb);
+  load8f<DT, PL>(img + (y1 * W + x0) * C, plane, c);
+  load8f<DT, PL>(img + (y1 * W + x1) * C, plane, d);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
-    store8f<DT, PL>(Y + pix * C + v * 8, plane, o);
-  }
+  for (int e = 0; e < 8; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
+  store8f<DT, PL>(Y + ((long long)blockIdx.y * Wo + ox) * C + v * 8, plane, o);
 }
 
 hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream) {
-  if (C % 8 != 0) return hipErrorInvalidValue;
-  const long long total = (long long)B * 4 * H * W * (C / 8);
-  const int grid = (int)min((total + 255) / 256, (long long)16384);
-  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((upsample2x_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)X,
-                                              (uint16_t*)Y, B, H, W, C, pl.act));
+  const int cvec = C / 8;
+  if (C % 8 != 0 || (cvec & (cvec - 1)) != 0 || (long long)H * W * C >= (1ll << 31)) return hipErrorInvalidValue;
+  int cshift = 0;
+  while ((1 << cshift) < cvec) ++cshift;
+  dim3 grid((2 * W * cvec + 255) / 256, B * 2 * H);
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((upsample2x_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X,
+                                              (uint16_t*)Y, B, H, W, C, cshift, pl.act));
   return hipGetLastError();
 }
 
