@@ -112,9 +112,19 @@ def main():
         gemm_ms = acc["gemm"][0] / P
         gemm_flop = 2.0 * GEMM_GMAC_PER_IMAGE[args.task] * 1e9 * args.batch
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+        # HBM traffic of the family per launch: PMC counters cannot be read inside this process, so the
+        # figure is the committed rocprofv3 measurement of this very command (profiles/README.md), scaled
+        # from its batch to this one; null when no measurement is committed for the dtype.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.dtype == "bf16":
+            tj = json.load(open(tpath))
+            traffic = round(tj["gemm_family_hbm_bytes_per_launch"] * args.batch / 32.0)
         roofline = {"bound": "mfma", "kernel": "dptx::gemm_kernel (implicit-GEMM MFMA, all conv/linear launches)",
                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes per gemm launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from the committed "
+                                    "rocprofv3 PMC passes (profiles/r01_pmc_traffic.json); algorithmic min ~ A+C+W bytes",
                     "launches_per_step": acc["gemm"][1], "avg_launch_ms": round(gemm_ms / max(1, acc["gemm"][1]), 5),
                     "algorithmic_gflop_per_step": round(gemm_flop / 1e9, 1),
                     "executed_gflop_per_step": round(2 * acc["gemm"][2] * args.batch / 1e9, 1)}
