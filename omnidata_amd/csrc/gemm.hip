@@ -37,6 +37,38 @@ template <int DT, int TM, int TN, bool RELU_A, int PL = 1>
 __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_lo, int b_lo, int wm, int wn, int lr, int lh,
                                          f32x16_t (&acc)[TM][TN]) {
   // a_lo / b_lo: byte distance of the lo-plane tiles inside the stage (PL == 2)
+  if constexpr (PL == 1) {
+    // all fragment reads of the k-tile are issued up front (16 ds_read_b128 in flight for a 64x64 wave tile,
+    // 64 VGPRs) and the MFMAs consume them behind counted lgkmcnt waits: the LDS latency is paid once per
+    // k-tile instead of once per k-step
+    u32x4_t af[BK / 16][TM], bf[BK / 16][TN];
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int chunk = 2 * ks + lh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + lr;
+        af[ks][i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + lr;
+        bf[ks][j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler otherwise sinks them
+                                        // back to one k-step of look-ahead to save registers)
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (RELU_A) af[ks][i] = relu8(af[ks][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = T16<DT>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ks = 0; ks < BK / 16; ++ks) {
     const int chunk = 2 * ks + lh;
@@ -527,6 +559,12 @@ template <int DT, int PL>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
   const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
+  {  // DPTX_TILE=12864 / 6464 forces a tile shape (occupancy experiments)
+    static int forced = -1;
+    if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
+    if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
+    if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
+  }
   if (p.N % 128 == 0 && m128 * (p.N / 128) >= 448) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
   if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1>(p, stream);
   if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 256, 64, 4, 1>(p, stream);
