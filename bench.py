@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (functional test of the N>1 path)")
+    ap.add_argument("--share-gpu", action="store_true", help="debug: all ranks use cuda:0 (needs --dist-backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -52,12 +54,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path exists only as HIP kernels (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from omnidata_amd.build import build
     if rank == 0 or not os.path.exists(os.path.join(ROOT, "omnidata_amd", "libdptx.so")):
