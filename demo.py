@@ -53,13 +53,16 @@ def main(argv=None):
             save_path = os.path.join(args.output_path, f"{output_file_name}_{args.task}.png")
             print(f"Reading input {img_path} ...")
             img = Image.open(img_path)
-            img_tensor = pp.image_to_input(img, args.task).to(device)
+            # Resize/CenterCrop/ToTensor(/Normalize) run on the GPU from the raw uint8 pixels (bit-identical to
+            # the PIL/torchvision path of the reference; RGBA and other modes fall back to PIL inside)
+            img_tensor = pp.image_to_input_gpu(img, args.task, device)
             pp.rgb_preview(img).save(os.path.join(args.output_path, f"{output_file_name}_rgb.png"))
             output = model(img_tensor).clamp(min=0, max=1)
             if args.task == "depth":
-                Image.fromarray(pp.depth_to_rgba(output)).save(save_path)
+                d512 = pp.depth_to_512_gpu(output)          # bicubic 384->512, clamp, 1-x on the GPU
+                Image.fromarray(pp.colorize_viridis(d512.cpu().numpy())).save(save_path)
             else:
-                pp.normal_to_pil(output[0]).save(save_path)
+                Image.fromarray(pp.normal_to_u8_gpu(output[0]).cpu().numpy()).save(save_path)
             print(f"Writing output {save_path} ...")
 
     img_path = Path(args.img_path)

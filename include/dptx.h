@@ -134,6 +134,22 @@ int dptx_profile_dump(dptx_handle h, const char* path);
 const char* dptx_last_error(dptx_handle h);
 const char* dptx_version(void);
 
+/* ---- GPU-side pre/post-processing of demo.py (no handle needed; all pointers are DEVICE pointers) ----
+ * dptx_preprocess_u8 replaces demo.py:74-76 / 92-95 / 130-138 for RGB (C=3) or greyscale (C=1) uint8 HWC images:
+ * Resize(384, BILINEAR, shorter side) with Pillow's antialiased 8-bit two-pass resampler (bit-identical),
+ * CenterCrop(384), ToTensor (/255), optional Normalize(0.5,0.5) (depth), 1->3 channel repeat.
+ * x_dev: [3,384,384] fp32.  Both image sides must be >= 1 and the resized image >= 384x384 (always true). */
+int dptx_preprocess_u8(const void* img_dev, int32_t H, int32_t W, int32_t C, int32_t row_stride_bytes,
+                       int32_t depth_normalize, void* x_dev, void* stream);
+/* demo.py:140,150: clamp(0,1) -> *255 -> uint8 (truncation), [3,384,384] fp32 -> [384,384,3] uint8. */
+int dptx_postprocess_normal_u8(const void* y_dev, void* rgb_u8_dev, void* stream);
+/* demo.py:143-145: bicubic 384->512 (align_corners=False), clamp(0,1), 1-x; [384,384] -> [512,512] fp32. */
+int dptx_postprocess_depth(const void* y_dev, void* out512_dev, void* stream);
+/* Host-side helper (exposed for tests): Pillow's fixed-point bilinear resampling coefficients for one axis.
+ * bounds: [out_size][2] (first tap, tap count); kk: [out_size][*ksize] 22-bit fixed-point weights. */
+int dptx_resample_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* kk, int32_t kk_capacity,
+                         int32_t* ksize);
+
 /* ---- op-level entry points (unit tests + micro-benchmarks of the individual kernels) ----
  * dtype: DPTX_DTYPE_*.  All pointers are device pointers; row-major / NHWC. */
 

@@ -45,6 +45,10 @@ ABI = [
     ("dptx_profile_dump", C.c_int, [_vp, C.c_char_p]),
     ("dptx_last_error", C.c_char_p, [_vp]),
     ("dptx_version", C.c_char_p, []),
+    ("dptx_preprocess_u8", C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    ("dptx_postprocess_normal_u8", C.c_int, [_vp, _vp, _vp]),
+    ("dptx_postprocess_depth", C.c_int, [_vp, _vp, _vp]),
+    ("dptx_resample_coeffs", C.c_int, [_i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i32, C.POINTER(C.c_int32)]),
     ("dptx_op_set_planes", C.c_int, [C.c_int64, C.c_int64]),
     ("dptx_op_gemm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("dptx_op_conv", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [_vp]),

@@ -36,7 +36,7 @@ def center_crop(img: Image.Image, size: int) -> Image.Image:
 
 
 def to_tensor(img: Image.Image) -> torch.Tensor:
-    a = np.asarray(img)
+    a = np.array(img)  # writable copy
     if a.ndim == 2:
         a = a[:, :, None]
     t = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1)
@@ -66,6 +66,14 @@ def normal_to_pil(output: torch.Tensor) -> Image.Image:
     return Image.fromarray(a)
 
 
+def colorize_viridis(o: np.ndarray) -> np.ndarray:
+    """plt.imsave(cmap='viridis') of a [H,W] array: normalise to the data range, apply the colormap, RGBA uint8."""
+    from matplotlib import cm
+    lo, hi = float(o.min()), float(o.max())
+    n = (o - lo) / (hi - lo) if hi > lo else np.zeros_like(o)
+    return (cm.get_cmap("viridis")(n) * 255).astype(np.uint8)
+
+
 def depth_to_rgba(output: torch.Tensor) -> np.ndarray:
     """[1,H,W] or [H,W] clamped depth -> bicubic 512x512 -> clamp -> 1-x -> viridis RGBA uint8."""
     from matplotlib import cm
@@ -75,3 +83,50 @@ def depth_to_rgba(output: torch.Tensor) -> np.ndarray:
     lo, hi = float(o.min()), float(o.max())  # plt.imsave normalises to [vmin, vmax] = data range
     n = (o - lo) / (hi - lo) if hi > lo else np.zeros_like(o)
     return (cm.get_cmap("viridis")(n) * 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------ GPU path (libdptx.so prepost kernels)
+def image_to_input_gpu(img, task: str, device="cuda:0") -> torch.Tensor:
+    """Same result as image_to_input() (bit-identical), computed on the GPU from the raw uint8 pixels: only the
+    undecoded image crosses PCIe.  RGB / greyscale uint8 images; other modes (RGBA is premultiplied by Pillow's
+    resize) take the PIL path."""
+    from .engine import load_library
+    if isinstance(img, Image.Image):
+        if img.mode not in ("RGB", "L"):
+            return image_to_input(img, task).to(device)
+        a = torch.from_numpy(np.array(img))
+    else:
+        a = img
+    if a.dim() == 2:
+        a = a[:, :, None]
+    assert a.dtype == torch.uint8 and a.shape[2] in (1, 3)
+    a = a.to(device).contiguous()
+    H, W, C = a.shape
+    x = torch.empty(1, 3, 384, 384, dtype=torch.float32, device=device)
+    rc = load_library().dptx_preprocess_u8(a.data_ptr(), H, W, C, W * C, int(task == "depth"), x.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"dptx_preprocess_u8 failed ({rc})")
+    return x
+
+
+def normal_to_u8_gpu(output: torch.Tensor) -> torch.Tensor:
+    """[3,384,384] float (cuda) -> [384,384,3] uint8 (cuda): clamp(0,1)*255 truncated, as ToPILImage does."""
+    from .engine import load_library
+    y = output.detach().float().contiguous()
+    out = torch.empty(384, 384, 3, dtype=torch.uint8, device=y.device)
+    rc = load_library().dptx_postprocess_normal_u8(y.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"dptx_postprocess_normal_u8 failed ({rc})")
+    return out
+
+
+def depth_to_512_gpu(output: torch.Tensor) -> torch.Tensor:
+    """[384,384] float (cuda) -> [512,512] float (cuda): bicubic, clamp(0,1), 1-x (demo.py:143-145)."""
+    from .engine import load_library
+    y = output.detach().float().reshape(384, 384).contiguous()
+    out = torch.empty(512, 512, dtype=torch.float32, device=y.device)
+    rc = load_library().dptx_postprocess_depth(y.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"dptx_postprocess_depth failed ({rc})")
+    return out
