@@ -47,7 +47,7 @@ enum { DPTX_IO_FP32 = 0 };
 
 typedef struct dptx_config {
   int32_t num_channels;  /* 3 = surface normals, 1 = depth (dpt_depth.py:88 num_channels)      */
-  int32_t max_batch;     /* arena is sized for this many 384x384 images per dptx_forward call   */
+  int32_t max_batch;     /* arena is sized for this many 384x384 images per dptx_forward call (1..48) */
   int32_t dtype;         /* DPTX_DTYPE_*                                                        */
   int32_t device_id;     /* HIP device ordinal; -1 = host-only handle (weight packing only)     */
   int32_t non_negative;  /* final ReLU of the head (dpt_depth.py:88,98 non_negative=True)       */

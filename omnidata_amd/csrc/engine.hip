@@ -663,7 +663,9 @@ void dptx_default_config(dptx_config* cfg) {
 int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (!out || !cfg) return DPTX_E_INVALID;
   *out = nullptr;
-  if ((cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 4096 ||
+  // max_batch <= 48: the largest activation (up-sampled head input, 37.7 MB/image) must stay below the 2 GB that a
+  // 32-bit buffer offset of the direct-to-LDS loads can address; callers chunk larger batches (model.py does).
+  if ((cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16 && cfg->dtype != DPTX_DTYPE_BF16X3) ||
       (cfg->ws_form != 0 && cfg->ws_form != 1))
     return DPTX_E_INVALID;

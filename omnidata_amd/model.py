@@ -55,7 +55,7 @@ class DPTDepthModel(BaseModel):
         self.non_negative = bool(non_negative)
         self.channels_last = channels_last  # accepted and, as in the reference (dpt_depth.py:68-69), a no-op
         self.engine_dtype = dtype
-        self.max_batch = int(max_batch)
+        self.max_batch = max(1, min(int(max_batch), 48))  # engine limit; larger batches are chunked in forward()
         init = random_state_dict(init_seed, num_channels)
         for key, shape in state_dict_spec(num_channels).items():
             *mods, leaf = key.split(".")
