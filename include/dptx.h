@@ -168,6 +168,10 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
                  void* Y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                  int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
                  int32_t Wo, int32_t a_relu, int32_t act, void* stream);
+/* Fused stem: x NCHW fp32 [B,3,H,W] -> y NHWC 16-bit [B,H/2,W/2,64] = conv 7x7 stride 2 with TF-SAME padding;
+ * Wt [64][176] 16-bit with k = (c*7 + ky)*8 + kx (kx = 7 and k >= 168 are zero).  H % 8 == 0, W % 128 == 0. */
+int dptx_op_stem_conv(int32_t dtype, const float* x, const void* Wt, void* y, int32_t B, int32_t H, int32_t W,
+                      void* stream);
 /* qkv[B*S,3*H*64] packed (which, head, dim) -> out[B*S,H*64]; softmax(q k^T / 8) v. */
 int dptx_op_attention(int32_t dtype, const void* qkv, void* out, int32_t B, int32_t S,
                       int32_t heads, void* stream);

@@ -175,7 +175,7 @@ inline size_t numel(const std::vector<int64_t>& s) {
 }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-constexpr int STEM_K = 192;  // 7*7*3 = 147 padded to 3 k-tiles of 64
+constexpr int STEM_K = 176;  // stem K axis ordered (c, ky, kx) with kx padded 7 -> 8 (168) and rounded up to 11 MFMA k-steps
 
 size_t packed_entry_bytes(const Spec& s) {
   switch (s.role) {
@@ -235,7 +235,7 @@ struct dptx_engine {
   double cat_macs[4] = {0, 0, 0, 0};
 
   // arena slices
-  Buf col, sraw, stem, S[3], T1, T2, PA, PB, DS, part[4], X, Hn, QKV, AO, F1, R3, R4, L3, T4, L4, clsb, lrn[4], tA, tB,
+  Buf sraw, stem, S[3], T1, T2, PA, PB, DS, part[4], X, Hn, QKV, AO, F1, R3, R4, L3, T4, L4, clsb, lrn[4], tA, tB,
       tC, P[4], H0, H0U, H1;
 
   int fail(int code, const std::string& m) {
@@ -263,7 +263,6 @@ void plan_arena(dptx_engine* e) {
     b.bytes = align_up(elems * esz, 256);
     off += b.bytes;
   };
-  take(e->col, B * 36864 * STEM_K, 2);
   take(e->sraw, B * 36864 * 64, 2);
   take(e->stem, B * 9216 * 64, 2);
   take(e->S[0], B * 9216 * 256, 2);
@@ -355,7 +354,9 @@ int pack_host(dptx_engine* e) {
         for (int kx = 0; kx < KW; ++kx)
           for (int i = 0; i < I; ++i) {
             const double wv = ((double)wo[((size_t)i * KH + ky) * KW + kx] - mean) * scale;
-            put(d16, (size_t)o * out_k + ((size_t)ky * KW + kx) * I + i, (float)wv);
+            // stem (stem.hip): k = (c*7 + ky)*8 + kx; every other conv: k = (ky*KW + kx)*I + c
+            const size_t kidx = stem ? ((size_t)i * 7 + ky) * 8 + kx : ((size_t)ky * KW + kx) * I + i;
+            put(d16, (size_t)o * out_k + kidx, (float)wv);
           }
     }
   }
@@ -451,16 +452,10 @@ int Run::forward(const float* x, float* y) {
   float* part2 = (float*)E->a(E->part[2]);
   float* part3 = (float*)E->a(E->part[3]);
 
-  // ---- stem: conv7x7 s2 SAME (im2col + GEMM) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
-  chk(launch_im2col_stem(dt, x, E->a(E->col), B, IMG, IMG, E->pl, st), "im2col_stem");
-  {
-    GemmParams p;
-    gemm_params_dense(p, B * 36864, 64, STEM_K);
-    p.A = E->a(E->col); p.W = E->w(bp + "stem.conv.weight"); p.C = E->a(E->sraw); p.planes = E->pl;
-    E->exec_macs += 36864.0 * 64 * STEM_K;
-    E->cat_macs[0] += 36864.0 * 64 * STEM_K;
-    chk(launch_gemm(dt, p, st), "stem.conv", 0);
-  }
+  // ---- stem: fused conv7x7 s2 SAME (stem.hip, no im2col) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
+  chk(launch_stem_conv(dt, x, E->w(bp + "stem.conv.weight"), E->a(E->sraw), B, IMG, IMG, E->pl, st), "stem.conv", 0);
+  E->exec_macs += 36864.0 * 64 * STEM_K;
+  E->cat_macs[0] += 36864.0 * 64 * STEM_K;
   gn_stats(E->a(E->sraw), part0, 36864, 64);
   chk(launch_gn_relu_maxpool(dt, E->a(E->sraw), E->a(E->stem), E->f(bp + "stem.norm.weight"), E->f(bp + "stem.norm.bias"),
                              part0, B, 192, 192, 64, 1e-5f, E->pl, st),
@@ -906,6 +901,10 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
   p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act; p.a_relu = a_relu; p.planes = g_op_planes;
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_stem_conv(int32_t dtype, const float* x, const void* Wt, void* y, int32_t B, int32_t H, int32_t W, void* stream) {
+  return launch_stem_conv(dtype, x, Wt, y, B, H, W, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
 int dptx_op_attention(int32_t dtype, const void* qkv, void* out, int32_t B, int32_t S, int32_t heads, void* stream) {

@@ -66,8 +66,8 @@ hipError_t launch_gn_apply(int mode, const GnParams& p, Planes pl, hipStream_t s
 hipError_t launch_gn_relu_maxpool(int mode, const void* X, void* Y, const float* gamma, const float* beta,
                                   const float* partial, int B, int H, int W, int C, float eps, Planes pl, hipStream_t stream);
 
-// stem im2col: x NCHW fp32 [B,3,H,W] -> col [B*Ho*Wo, 192] 16-bit, k = (ky*7+kx)*3 + c, TF-SAME pad
-hipError_t launch_im2col_stem(int mode, const float* x, void* col, int B, int H, int W, Planes pl, hipStream_t stream);
+// fused stem conv 7x7 s2 TF-SAME: x NCHW fp32 [B,3,H,W] -> y NHWC 16-bit [B,H/2,W/2,64]; Wt [64][176], k = (c*7+ky)*8 + kx
+hipError_t launch_stem_conv(int mode, const float* x, const void* Wt, void* y, int B, int H, int W, Planes pl, hipStream_t stream);
 
 // bilinear x2 align_corners=True on NHWC 16-bit
 hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream);

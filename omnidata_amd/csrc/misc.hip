@@ -1,47 +1,10 @@
-// misc.hip -- the HBM-bound glue kernels of the DPT-Hybrid forward: stem im2col, bilinear x2
+// misc.hip -- the HBM-bound glue kernels of the DPT-Hybrid forward: bilinear x2
 // (align_corners=True), the 32->C head projection writing NCHW fp32, cls-token rows, the cls
 // half of ProjectReadout, and an fp32 export for debug taps.
 #include "common.h"
 #include "kernels.h"
 
 namespace dptx {
-
-// ------------------------------------------------------------------------- stem im2col (7x7 s2)
-// x NCHW fp32 [B,3,H,W] -> col[B*Ho*Wo][192] 16-bit, k = (ky*7+kx)*3 + c (k >= 147 zero).
-// TF-SAME padding (timm StdConv2dSame): pad_total = (Ho-1)*2 + 7 - H, top/left = pad_total/2.
-template <int DT, int PL>
-__global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ x, uint16_t* __restrict__ col, int B,
-                                                          int H, int W, int Ho, int Wo, int pt, int pl, long long plane) {
-  // grid (ceil(Wo*24/256), B*Ho): blockIdx.y = (b, oy); thread = (ox, j) with j the 8-wide k chunk
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Wo * 24) return;
-  const int ox = idx / 24, j = idx - ox * 24;
-  const int b = blockIdx.y / Ho, oy = blockIdx.y - b * Ho;
-  float f[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = j * 8 + e;
-    float val = 0.f;
-    if (k < 147) {
-      const int tap = k / 3, c = k - tap * 3;
-      const int ky = tap / 7, kx = tap - ky * 7;
-      const int iy = 2 * oy + ky - pt, ix = 2 * ox + kx - pl;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) val = x[((b * 3 + c) * H + iy) * W + ix];
-    }
-    f[e] = val;
-  }
-  store8f<DT, PL>(col + ((long long)blockIdx.y * Wo + ox) * 192 + j * 8, plane, f);
-}
-
-hipError_t launch_im2col_stem(int mode, const float* x, void* col, int B, int H, int W, Planes pl, hipStream_t stream) {
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  const int pth = max((Ho - 1) * 2 + 7 - H, 0), ptw = max((Wo - 1) * 2 + 7 - W, 0);
-  if ((long long)B * 3 * H * W >= (1ll << 31)) return hipErrorInvalidValue;
-  dim3 grid((Wo * 24 + 255) / 256, B * Ho);
-  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((im2col_stem_kernel<DT, PL>), grid, dim3(256), 0, stream, x, (uint16_t*)col, B,
-                                              H, W, Ho, Wo, pth / 2, ptw / 2, pl.act));
-  return hipGetLastError();
-}
 
 // ------------------------------------------------------------------ bilinear x2, align_corners
 // blocks.py:335-337 / dpt_depth.py:93: F.interpolate(scale_factor=2, mode="bilinear",

@@ -52,6 +52,7 @@ ABI = [
     ("dptx_op_set_planes", C.c_int, [C.c_int64, C.c_int64]),
     ("dptx_op_gemm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("dptx_op_conv", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [_vp]),
+    ("dptx_op_stem_conv", C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_op_attention", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_op_layernorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
     ("dptx_op_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp]),

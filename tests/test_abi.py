@@ -70,7 +70,7 @@ def _blob_offsets(spec_items, dtype_bytes=2):
             continue
         n = int(np.prod(shape))
         if k.endswith("stem.conv.weight"):
-            b = 64 * 192 * 2
+            b = 64 * 176 * 2
         elif k == "scratch.output_conv.4.weight":
             b = n * 4
         elif k.endswith(".weight") and len(shape) >= 2:
@@ -113,12 +113,13 @@ def test_packed_weights_match_numpy_fold(built_lib, dtype):
         tol = 2.0 ** (-8 if dtype == "bf16" else -11) * ref.abs().clamp_min(1e-3)  # <= 1 ulp: fold done in double
         assert bool(((got - ref).abs() <= tol).all())
         assert (got - ref.float().to(tdt).double()).abs().max() <= 2.0 ** (-7 if dtype == "bf16" else -10) * ref.abs().max()
-    # stem: [64][192], k = (ky*7+kx)*3 + c, zero padded from 147
+    # stem: [64][176], k = (c*7 + ky)*8 + kx with kx padded 7 -> 8 and K padded 168 -> 176 (zeros)
     k = "pretrained.model.patch_embed.backbone.stem.conv.weight"
-    got = packed16(k, 64 * 192).reshape(64, 192)
-    ref = standardize_weight(sd[k].double(), 1e-8, "timm04").permute(0, 2, 3, 1).reshape(64, 147)
-    assert torch.all(got[:, 147:] == 0)
-    assert (got[:, :147].double() - ref).abs().max() <= 2.0 ** (-7 if dtype == "bf16" else -10) * ref.abs().max()
+    got = packed16(k, 64 * 176).reshape(64, 176)
+    ref = standardize_weight(sd[k].double(), 1e-8, "timm04")                     # [64,3,7,7] (o,c,ky,kx)
+    g4 = got[:, :168].reshape(64, 3, 7, 8)
+    assert torch.all(got[:, 168:] == 0) and torch.all(g4[..., 7] == 0)
+    assert (g4[..., :7].double() - ref).abs().max() <= 2.0 ** (-7 if dtype == "bf16" else -10) * ref.abs().max()
     # fp32 vectors verbatim
     for k in ("pretrained.model.pos_embed", "scratch.output_conv.4.weight", "pretrained.model.blocks.0.norm1.bias"):
         o, b = offs[k]

@@ -152,3 +152,20 @@ def test_upsample2x_align_corners(dtype, B, H, C):
     assert lib.dptx_op_upsample2x(DTYPES[dtype], ptr(X), ptr(Y), B, H, H, C, stream()) == 0
     ref = F.interpolate(X.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
     assert rel_err(Y.float(), ref) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,W", [(2, 384, 384), (1, 64, 128), (3, 96, 256)])
+def test_fused_stem_conv(dtype, B, H, W):
+    """7x7 stride-2 TF-SAME conv straight from the NCHW fp32 image (no im2col)."""
+    lib = load_library()
+    x = torch.rand(B, 3, H, W, device=DEV)
+    w = torch.randn(64, 3, 7, 7, device=DEV) * 147 ** -0.5
+    wp = torch.zeros(64, 176, device=DEV)
+    wp[:, :168].view(64, 3, 7, 8)[..., :7] = w                   # k = (c*7 + ky)*8 + kx
+    wp = wp.to(TDT[dtype])
+    y = torch.empty(B, H // 2, W // 2, 64, device=DEV, dtype=TDT[dtype])
+    assert lib.dptx_op_stem_conv(DTYPES[dtype], ptr(x), ptr(wp), ptr(y), B, H, W, stream()) == 0
+    ref = F.conv2d(F.pad(x.to(TDT[dtype]).float(), [2, 3, 2, 3]), w.to(TDT[dtype]).float(), None, 2).permute(0, 2, 3, 1)
+    assert ref.shape == y.shape
+    assert rel_err(y.float(), ref) < OUT_TOL[dtype]
