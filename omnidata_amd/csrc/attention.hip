@@ -3,7 +3,7 @@
 //
 // Input  qkv[B*S][3*H*64] 16-bit, feature index = which*H*64 + head*64 + dim (timm's
 //        reshape(B,N,3,heads,64) packing); output out[B*S][H*64] 16-bit.
-// Grid   (ceil(S/128), H, B); 4 waves, each owns 32 query rows.
+// Grid   1-D, ceil(S/128) * B * H blocks (q-block slowest: K/V sharers stay on one XCD); 4 waves x 32 query rows.
 // Per 64-key tile (shared by the 4 waves through LDS):
 //   K  tile [64 keys][64 d]   row-major, 16-B chunks XOR-swizzled (same scheme as gemm.hip)
 //   V^T tile [64 d][64 keys]  transposed while staging (two adjacent keys per ds_write_b32),
@@ -34,12 +34,15 @@ __device__ __forceinline__ int vt_pos(int key) {  // swap bits 2 and 3
 // (lo*hi + hi*lo + hi*hi); `plane` is the element distance between the planes of qkv / out.
 template <int DT, int PL>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                           int S, int H, long long plane) {
+                                                           int S, int H, int BH, long long plane) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x PL x (K tile + V^T tile)
   constexpr int STAGE = ATT_STAGE * PL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, id = qblock * (B*H) + (b*H + head): the q-blocks that re-read one (batch, head)'s K/V have ids that
+  // differ by B*H (a multiple of 8 for even B), i.e. they run on the same XCD and share its L2
+  const int bh = (int)blockIdx.x % BH, qblk = (int)blockIdx.x / BH;
+  const int head = bh % H, b = bh / H;
   const int ld = 3 * H * ATT_D;
   const long long row0 = (long long)b * S;
   const uint16_t* qbase = qkv + head * ATT_D;
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   const uint16_t* vbase = qkv + 2 * H * ATT_D + head * ATT_D;
 
   // Q fragments (B operand: lane = query column, 8 consecutive d per k-step)
-  const int q = blockIdx.x * 128 + wave * 32 + lr;
+  const int q = qblk * 128 + wave * 32 + lr;
   const int qc = q < S ? q : S - 1;
   uint4 qf[4], ql[4];
 #pragma unroll
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         const uint32_t a = (e & 1) ? (w0[e >> 1] >> 16) : (w0[e >> 1] & 0xffffu);             \
         const uint32_t c = (e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu);             \
         const int d = kc * 8 + e;                                                             \
-        *(uint32_t*)(sv + d * 128 + ((((pos >> 3) ^ ((d >> 1) & 7))) << 4) + (pos & 7) * 2) = a | (c << 16); \
+        *(uint32_t*)(sv + d * 128 + ((((pos >> 3) ^ ((d >> 1) & 7) ^ ((d >> 4) & 3))) << 4) + (pos & 7) * 2) = a | (c << 16); \
       }                                                                                       \
     }                                                                                         \
   } while (0)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         for (int dt = 0; dt < 2; ++dt) {
           const int drow = dt * 32 + lr;
           const int vchunk = sub * 4 + s2 * 2 + lh;
-          const int voff = drow * 128 + ((vchunk ^ ((drow >> 1) & 7)) << 4);
+          const int voff = drow * 128 + ((vchunk ^ ((drow >> 1) & 7) ^ ((drow >> 4) & 3)) << 4);
           const uint4 vf = *(const uint4*)(sv + voff);
           if (PL == 2) {
             const uint4 vl = *(const uint4*)(sv + ATT_STAGE + voff);
@@ -216,18 +219,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
 }
 
 hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, int heads, Planes pl, hipStream_t stream) {
-  dim3 grid((S + 127) / 128, heads, B);
+  const int BH = B * heads;
+  dim3 grid(((S + 127) / 128) * BH);
   if (mode == MODE_BF16)
-    hipLaunchKernelGGL((attention_kernel<DT_BF16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, 0ll);
+    hipLaunchKernelGGL((attention_kernel<DT_BF16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, 0ll);
   else if (mode == MODE_FP16)
-    hipLaunchKernelGGL((attention_kernel<DT_FP16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, 0ll);
+    hipLaunchKernelGGL((attention_kernel<DT_FP16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, 0ll);
   else if (mode == MODE_BF16X3) {
     static bool done = false;
     if (!done) {
       (void)hipFuncSetAttribute((const void*)attention_kernel<DT_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE);
       done = true;
     }
-    hipLaunchKernelGGL((attention_kernel<DT_BF16, 2>), grid, dim3(256), 4 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, pl.act);
+    hipLaunchKernelGGL((attention_kernel<DT_BF16, 2>), grid, dim3(256), 4 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, pl.act);
   } else
     return hipErrorInvalidValue;
   return hipGetLastError();
