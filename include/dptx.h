@@ -47,13 +47,15 @@ enum { DPTX_IO_FP32 = 0 };
 
 typedef struct dptx_config {
   int32_t num_channels;  /* 3 = surface normals, 1 = depth (dpt_depth.py:88 num_channels)      */
-  int32_t max_batch;     /* arena is sized for this many 384x384 images per dptx_forward call (1..48) */
+  int32_t max_batch;     /* arena is sized for this many max_height x max_width images per call (1..48) */
   int32_t dtype;         /* DPTX_DTYPE_*                                                        */
   int32_t device_id;     /* HIP device ordinal; -1 = host-only handle (weight packing only)     */
   int32_t non_negative;  /* final ReLU of the head (dpt_depth.py:88,98 non_negative=True)       */
   int32_t ws_form;       /* 0: (w-mean)/(std+eps) timm 0.4.x;  1: (w-mean)/sqrt(var+eps)        */
   float   ws_eps;        /* StdConv2dSame eps (timm vit_base_r50_s16: 1e-8)                     */
-  int32_t reserved[8];   /* must be zero                                                        */
+  int32_t max_height;    /* largest input the arena is planned for; 0 = 384. Multiples of 32,   */
+  int32_t max_width;     /*   >= 64, and max_batch*max_height*max_width*256 < 2^31 (see dptx_forward_hw) */
+  int32_t reserved[6];   /* must be zero                                                        */
 } dptx_config;
 
 /* Fills *cfg with the reference defaults: C=3, max_batch=32, bf16, device 0, non_negative=1,
@@ -103,6 +105,16 @@ size_t dptx_workspace_bytes(dptx_handle h);
  * Asynchronous on `stream` (a hipStream_t; NULL = default stream). 1 <= batch <= max_batch. */
 int dptx_forward(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev,
                  int32_t batch, void* stream);
+
+/* Same forward at another input size: what the reference does when DPTDepthModel is fed a tensor
+ * that is not 384x384 -- forward_flex (vit.py:119-155) resamples pos_embed to the (height/16, width/16)
+ * patch grid with _resize_pos_embed (vit.py:102-116, bilinear, align_corners=False) and everything else
+ * is convolutional.  height, width: multiples of 32 (the reference's own constraint: the 1/32-scale map is
+ * up-sampled x2 and added to the 1/16-scale map), >= 64, height*width <= max_height*max_width of the config.
+ *   x_dev [batch,3,height,width] NCHW fp32  ->  y_dev [batch,C,height,width] NCHW fp32.
+ * dptx_forward(...) == dptx_forward_hw(..., 384, 384, ...). */
+int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev,
+                    int32_t batch, int32_t height, int32_t width, void* stream);
 
 /* Debug hook for stage-level parity (SURVEY.md A.1 tap names: "stem","s0","s1","s2","tok0",
  * "blk0".."blk11","l3","l4","l1_rn".."l4_rn","p4","p3","p2","p1","h0","h1").  Copies the

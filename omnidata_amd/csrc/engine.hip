@@ -221,6 +221,7 @@ struct dptx_engine {
   std::string err;
   std::map<std::string, TapInfo> taps;
   bool taps_on = false;
+  size_t tok_tap_stride = 0;      // floats per token-stream snapshot
   float* d_tok_taps = nullptr;  // [13][B*577*768] fp32 copies of the token stream (taps_on)
   int64_t launches = 0;
   double exec_macs = 0.0;
@@ -235,6 +236,9 @@ struct dptx_engine {
   double cat_macs[4] = {0, 0, 0, 0};
 
   // arena slices
+  int max_h = 384, max_w = 384;   // largest supported input (cfg.max_height/max_width; 0 = 384)
+  int pos_gh = 0, pos_gw = 0;     // grid of the resized pos_embed currently held in pos_alt
+  Buf pos_alt;
   Buf sraw, stem, S[3], T1, T2, PA, PB, DS, part[4], X, Hn, QKV, AO, F1, R3, R4, L3, T4, L4, clsb, lrn[4], tA, tB,
       tC, P[4], H0, H0U, H1;
 
@@ -257,44 +261,48 @@ namespace {
 
 void plan_arena(dptx_engine* e) {
   const size_t B = (size_t)e->cfg.max_batch;
+  // every buffer scales with the pixel count of the largest supported input (H, W multiples of 32); P = H*W
+  const size_t P = (size_t)e->max_h * e->max_w;
+  const size_t p2 = P / 4, p4 = P / 16, p8 = P / 64, p16 = P / 256, p32 = P / 1024, S = p16 + 1;
   size_t off = 0;
   auto take = [&](Buf& b, size_t elems, size_t esz) {
     b.off = off;
     b.bytes = align_up(elems * esz, 256);
     off += b.bytes;
   };
-  take(e->sraw, B * 36864 * 64, 2);
-  take(e->stem, B * 9216 * 64, 2);
-  take(e->S[0], B * 9216 * 256, 2);
-  take(e->S[1], B * 2304 * 512, 2);
-  take(e->S[2], B * 576 * 1024, 2);
-  take(e->T1, B * 9216 * 128, 2);  // largest conv1 output: stage1 block0 (128 ch @96^2)
-  take(e->T2, B * 9216 * 64, 2);   // largest conv2 output: stage0 (64 ch @96^2)
-  take(e->PA, B * 9216 * 256, 2);
-  take(e->PB, B * 9216 * 256, 2);
-  take(e->DS, B * 9216 * 256, 2);
-  for (int i = 0; i < 4; ++i) take(e->part[i], B * 144 * 64, 4);
-  take(e->X, B * S_TOK * D_VIT, 4);
-  take(e->Hn, B * S_TOK * D_VIT, 2);
-  take(e->QKV, B * S_TOK * 3 * D_VIT, 2);
-  take(e->AO, B * S_TOK * D_VIT, 2);
-  take(e->F1, B * S_TOK * D_MLP, 2);
-  take(e->R3, B * 576 * D_VIT, 2);
-  take(e->R4, B * 576 * D_VIT, 2);
-  take(e->L3, B * 576 * D_VIT, 2);
-  take(e->T4, B * 576 * D_VIT, 2);
-  take(e->L4, B * 144 * D_VIT, 2);
+  take(e->sraw, B * p2 * 64, 2);
+  take(e->stem, B * p4 * 64, 2);
+  take(e->S[0], B * p4 * 256, 2);
+  take(e->S[1], B * p8 * 512, 2);
+  take(e->S[2], B * p16 * 1024, 2);
+  take(e->T1, B * p4 * 128, 2);  // largest conv1 output: stage1 block0 (128 ch @ 1/4 resolution)
+  take(e->T2, B * p4 * 64, 2);   // largest conv2 output: stage0 (64 ch @ 1/4 resolution)
+  take(e->PA, B * p4 * 256, 2);
+  take(e->PB, B * p4 * 256, 2);
+  take(e->DS, B * p4 * 256, 2);
+  for (int i = 0; i < 4; ++i) take(e->part[i], B * (p2 / 256 + 64) * 64, 4);
+  take(e->X, B * S * D_VIT, 4);
+  take(e->Hn, B * S * D_VIT, 2);
+  take(e->QKV, B * S * 3 * D_VIT, 2);
+  take(e->AO, B * S * D_VIT, 2);
+  take(e->F1, B * S * D_MLP, 2);
+  take(e->R3, B * p16 * D_VIT, 2);
+  take(e->R4, B * p16 * D_VIT, 2);
+  take(e->L3, B * p16 * D_VIT, 2);
+  take(e->T4, B * p16 * D_VIT, 2);
+  take(e->L4, B * p32 * D_VIT, 2);
   take(e->clsb, B * D_VIT, 4);
-  const size_t rn_px[4] = {9216, 2304, 576, 144};
+  take(e->pos_alt, S * D_VIT, 4);  // bilinearly resized pos_embed for inputs other than 384x384
+  const size_t rn_px[4] = {p4, p8, p16, p32};
   for (int i = 0; i < 4; ++i) take(e->lrn[i], B * rn_px[i] * FEAT, 2);
-  take(e->tA, B * 9216 * FEAT, 2);
-  take(e->tB, B * 9216 * FEAT, 2);
-  take(e->tC, B * 9216 * FEAT, 2);
-  const size_t p_px[4] = {36864, 9216, 2304, 576};  // P[0]=path_1 (192^2) ... P[3]=path_4 (24^2)
+  take(e->tA, B * p4 * FEAT, 2);
+  take(e->tB, B * p4 * FEAT, 2);
+  take(e->tC, B * p4 * FEAT, 2);
+  const size_t p_px[4] = {p2, p4, p8, p16};  // P[0]=path_1 (1/2 res) ... P[3]=path_4 (1/16 res)
   for (int i = 0; i < 4; ++i) take(e->P[i], B * p_px[i] * FEAT, 2);
-  take(e->H0, B * 36864 * 128, 2);
-  take(e->H0U, B * 147456 * 128, 2);
-  take(e->H1, B * 147456 * 32, 2);
+  take(e->H0, B * p2 * 128, 2);
+  take(e->H0U, B * P * 128, 2);
+  take(e->H1, B * P * 32, 2);
   e->arena_single = off;
   const int npl = e->cfg.dtype == DPTX_DTYPE_BF16X3 ? 2 : 1;
   e->arena_bytes = off * npl;
@@ -370,6 +378,7 @@ struct Run {
   int B;
   hipStream_t st;
   int dt;
+  int Hi = 384, Wi = 384;  // input size (multiples of 32)
   hipError_t err = hipSuccess;
   const char* where = "";
 
@@ -422,9 +431,9 @@ struct Run {
   }
 
   // RCU (blocks.py:263-286): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
-  void rcu(const std::string& p, const void* x, int H, void* tmp, void* out, const void* extra) {
-    conv(x, H, H, FEAT, p + "conv1.weight", 3, 1, 1, 1, H, H, FEAT, tmp, e->f(p + "conv1.bias"), /*act*/ 1, /*a_relu*/ 1);
-    conv(tmp, H, H, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, H, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra);
+  void rcu(const std::string& p, const void* x, int H, int W, void* tmp, void* out, const void* extra) {
+    conv(x, H, W, FEAT, p + "conv1.weight", 3, 1, 1, 1, H, W, FEAT, tmp, e->f(p + "conv1.bias"), /*act*/ 1, /*a_relu*/ 1);
+    conv(tmp, H, W, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, W, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra);
   }
 
   int forward(const float* x, float* y);
@@ -451,74 +460,84 @@ int Run::forward(const float* x, float* y) {
   float* part1 = (float*)E->a(E->part[1]);
   float* part2 = (float*)E->a(E->part[2]);
   float* part3 = (float*)E->a(E->part[3]);
+  const int h2 = Hi / 2, w2 = Wi / 2, h4 = Hi / 4, w4 = Wi / 4, gh = Hi / 16, gw = Wi / 16, h32 = Hi / 32, w32 = Wi / 32;
+  const int NP = gh * gw;   // patch tokens per image (576 at 384x384)
+  const int S = NP + 1;     // + cls
+  const bool native = (gh == 24 && gw == 24);
+  const float* pos = E->f("pretrained.model.pos_embed");
+  if (!native) {  // vit.py:119-125: forward_flex resizes pos_embed to the input's patch grid on every call
+    chk(launch_pos_resize(pos, (float*)E->a(E->pos_alt), 24, gh, gw, D_VIT, st), "pos_resize");
+    pos = (const float*)E->a(E->pos_alt);
+  }
 
   // ---- stem: fused conv7x7 s2 SAME (stem.hip, no im2col) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
-  chk(launch_stem_conv(dt, x, E->w(bp + "stem.conv.weight"), E->a(E->sraw), B, IMG, IMG, E->pl, st), "stem.conv", 0);
-  E->exec_macs += 36864.0 * 64 * STEM_K;
-  E->cat_macs[0] += 36864.0 * 64 * STEM_K;
-  gn_stats(E->a(E->sraw), part0, 36864, 64);
+  chk(launch_stem_conv(dt, x, E->w(bp + "stem.conv.weight"), E->a(E->sraw), B, Hi, Wi, E->pl, st), "stem.conv", 0);
+  E->exec_macs += (double)h2 * w2 * 64 * STEM_K;
+  E->cat_macs[0] += (double)h2 * w2 * 64 * STEM_K;
+  gn_stats(E->a(E->sraw), part0, h2 * w2, 64);
   chk(launch_gn_relu_maxpool(dt, E->a(E->sraw), E->a(E->stem), E->f(bp + "stem.norm.weight"), E->f(bp + "stem.norm.bias"),
-                             part0, B, 192, 192, 64, 1e-5f, E->pl, st),
+                             part0, B, h2, w2, 64, 1e-5f, E->pl, st),
       "stem.pool", 2);
-  tap("stem", E->a(E->stem), 96, 96, 64);
+  tap("stem", E->a(E->stem), h4, w4, 64);
 
   // ---- ResNetV2 stages (3,4,9) non-preact bottlenecks -----------------------------------
   const void* cur = E->a(E->stem);
-  int H = 96, cin = 64;
+  int H = h4, Wd = w4, cin = 64;
   for (int s = 0; s < 3; ++s) {
     const int cout = STAGE_OUT[s], mid = cout / 4;
     for (int b = 0; b < STAGE_DEPTH[s]; ++b) {
       const std::string p = bp + "stages." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
       const int stride = (b == 0) ? STAGE_STRIDE[s] : 1;
-      const int Ho = H / stride;
+      const int Ho = H / stride, Wo = Wd / stride;
       void* out = (b == STAGE_DEPTH[s] - 1) ? (void*)E->a(E->S[s]) : (void*)((b & 1) ? E->a(E->PB) : E->a(E->PA));
       if (b == 0) {
-        conv(cur, H, H, cin, p + "downsample.conv.weight", 1, stride, 0, 0, Ho, Ho, cout, E->a(E->DS), nullptr, 0, 0);
-        gn_stats(E->a(E->DS), part3, Ho * Ho, cout);
+        conv(cur, H, Wd, cin, p + "downsample.conv.weight", 1, stride, 0, 0, Ho, Wo, cout, E->a(E->DS), nullptr, 0, 0);
+        gn_stats(E->a(E->DS), part3, Ho * Wo, cout);
       }
-      conv(cur, H, H, cin, p + "conv1.weight", 1, 1, 0, 0, H, H, mid, E->a(E->T1), nullptr, 0, 0);
-      gn_stats(E->a(E->T1), part0, H * H, mid);
-      gn_apply(E->a(E->T1), p + "norm1", part0, H * H, mid, 1);
+      conv(cur, H, Wd, cin, p + "conv1.weight", 1, 1, 0, 0, H, Wd, mid, E->a(E->T1), nullptr, 0, 0);
+      gn_stats(E->a(E->T1), part0, H * Wd, mid);
+      gn_apply(E->a(E->T1), p + "norm1", part0, H * Wd, mid, 1);
       // 3x3, stride on conv2 (V1.5); TF-SAME: s1 -> pad (1,1); s2 on even H -> pad (0,1)
       const int pad = (stride == 1) ? 1 : 0;
-      conv(E->a(E->T1), H, H, mid, p + "conv2.weight", 3, stride, pad, pad, Ho, Ho, mid, E->a(E->T2), nullptr, 0, 0);
-      gn_stats(E->a(E->T2), part1, Ho * Ho, mid);
-      gn_apply(E->a(E->T2), p + "norm2", part1, Ho * Ho, mid, 1);
-      conv(E->a(E->T2), Ho, Ho, mid, p + "conv3.weight", 1, 1, 0, 0, Ho, Ho, cout, out, nullptr, 0, 0);
-      gn_stats(out, part2, Ho * Ho, cout);
+      conv(E->a(E->T1), H, Wd, mid, p + "conv2.weight", 3, stride, pad, pad, Ho, Wo, mid, E->a(E->T2), nullptr, 0, 0);
+      gn_stats(E->a(E->T2), part1, Ho * Wo, mid);
+      gn_apply(E->a(E->T2), p + "norm2", part1, Ho * Wo, mid, 1);
+      conv(E->a(E->T2), Ho, Wo, mid, p + "conv3.weight", 1, 1, 0, 0, Ho, Wo, cout, out, nullptr, 0, 0);
+      gn_stats(out, part2, Ho * Wo, cout);
       if (b == 0)
-        gn_apply(out, p + "norm3", part2, Ho * Ho, cout, 1, E->a(E->DS), p + "downsample.norm", part3);
+        gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, E->a(E->DS), p + "downsample.norm", part3);
       else
-        gn_apply(out, p + "norm3", part2, Ho * Ho, cout, 1, cur);
+        gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, cur);
       cur = out;
       H = Ho;
+      Wd = Wo;
       cin = cout;
     }
     const char* names[3] = {"s0", "s1", "s2"};
-    tap(names[s], cur, H, H, cout);
+    tap(names[s], cur, H, Wd, cout);
   }
 
   // ---- tokens: 1x1 proj + bias + pos_embed -> fp32 stream X[b*577 + 1 + p]; cls rows ----
   float* X = (float*)E->a(E->X);
   {
     GemmParams p;
-    gemm_params_dense(p, B * 576, D_VIT, 1024);
+    gemm_params_dense(p, B * NP, D_VIT, 1024);
     p.A = E->a(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
     p.bias = E->f(vp + "patch_embed.proj.bias");
-    p.c_rpi = 576; p.c_img_rows = S_TOK; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
-    p.R2 = E->f(vp + "pos_embed"); p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
-    E->exec_macs += 576.0 * D_VIT * 1024;
-    E->cat_macs[0] += 576.0 * D_VIT * 1024;
+    p.c_rpi = NP; p.c_img_rows = S; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
+    p.R2 = pos; p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
+    E->exec_macs += (double)NP * D_VIT * 1024;
+    E->cat_macs[0] += (double)NP * D_VIT * 1024;
     chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
   }
-  chk(launch_cls_rows(E->f(vp + "cls_token"), E->f(vp + "pos_embed"), X, B, S_TOK, D_VIT, st), "cls_rows");
-  const int M = B * S_TOK;
+  chk(launch_cls_rows(E->f(vp + "cls_token"), pos, X, B, S, D_VIT, st), "cls_rows");
+  const int M = B * S;
   const size_t tok_elems = (size_t)M * D_VIT;
   auto tok_tap = [&](int idx, const char* name) {
     if (!E->taps_on) return;
-    float* dst = E->d_tok_taps + (size_t)idx * (size_t)E->cfg.max_batch * S_TOK * D_VIT;
+    float* dst = E->d_tok_taps + (size_t)idx * E->tok_tap_stride;
     if (err == hipSuccess) err = hipMemcpyAsync(dst, X, tok_elems * 4, hipMemcpyDeviceToDevice, st);
-    E->taps[name] = TapInfo{dst, {B, S_TOK, D_VIT, 1}, true};
+    E->taps[name] = TapInfo{dst, {B, S, D_VIT, 1}, true};
   };
   tok_tap(0, "tok0");
 
@@ -528,8 +547,8 @@ int Run::forward(const float* x, float* y) {
     gemm_params_dense(p, M, N, K);
     p.A = A; p.a_fp32 = a_fp32; p.W = E->w(wkey); p.C = C; p.c_fp32 = c_fp32; p.bias = bias; p.act = act;
     p.R1 = R1; p.r1_fp32 = r1_fp32; p.planes = E->pl;
-    E->exec_macs += (double)S_TOK * N * K;
-    E->cat_macs[0] += (double)S_TOK * N * K;
+    E->exec_macs += (double)S * N * K;
+    E->cat_macs[0] += (double)S * N * K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
   };
 
@@ -537,32 +556,32 @@ int Run::forward(const float* x, float* y) {
   auto readout = [&](int n) {
     const std::string pp = "pretrained.act_postprocess" + std::to_string(n) + ".";
     float* clsb = (float*)E->a(E->clsb);
-    chk(launch_readout_cls(dt, X, (long long)S_TOK * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT, D_VIT,
+    chk(launch_readout_cls(dt, X, (long long)S * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT, D_VIT,
                            E->f(pp + "0.project.0.bias"), clsb, B, D_VIT, D_VIT, E->pl, st),
         "readout_cls");
     // the token GEMM reads a 16-bit image of the fp32 stream (Hn is free between blocks)
-    chk(launch_cast_f32(dt, X, E->a(E->Hn), (size_t)B * S_TOK * D_VIT, E->pl, st), "readout_cast");
+    chk(launch_cast_f32(dt, X, E->a(E->Hn), (size_t)B * S * D_VIT, E->pl, st), "readout_cast");
     E->exec_macs += (double)D_VIT * D_VIT;  // per image
     void* R = (n == 3) ? E->a(E->R3) : E->a(E->R4);
     GemmParams p{};
-    p.A = E->a(E->Hn); p.a_bytes = (long long)B * S_TOK * D_VIT * 2; p.planes = E->pl;
+    p.A = E->a(E->Hn); p.a_bytes = (long long)B * S * D_VIT * 2; p.planes = E->pl;
     p.W = E->w(pp + "0.project.0.weight"); p.ldw = 2 * D_VIT; p.C = R;
-    p.M = B * 576; p.N = D_VIT; p.K = D_VIT;
-    p.a_rpi = 576; p.Wout = 576; p.Hin = 1; p.Win = 576; p.Cin = D_VIT; p.a_pix_stride = D_VIT;
-    p.a_img_stride = (long long)S_TOK * D_VIT; p.a_off = D_VIT;  // skip the cls row
+    p.M = B * NP; p.N = D_VIT; p.K = D_VIT;
+    p.a_rpi = NP; p.Wout = NP; p.Hin = 1; p.Win = NP; p.Cin = D_VIT; p.a_pix_stride = D_VIT;
+    p.a_img_stride = (long long)S * D_VIT; p.a_off = D_VIT;  // skip the cls row
     p.ksz = 1; p.stride = 1;
-    p.c_rpi = 576; p.c_img_rows = 576; p.c_row_off = 0; p.ldc = D_VIT;
+    p.c_rpi = NP; p.c_img_rows = NP; p.c_row_off = 0; p.ldc = D_VIT;
     p.bias = clsb; p.bias_per_img = 1; p.act = 2;
-    E->exec_macs += 576.0 * D_VIT * D_VIT;
-    E->cat_macs[0] += 576.0 * D_VIT * D_VIT;
+    E->exec_macs += (double)NP * D_VIT * D_VIT;
+    E->cat_macs[0] += (double)NP * D_VIT * D_VIT;
     chk(launch_gemm(dt, p, st), "readout", 0);
     if (n == 3) {
-      conv(R, 24, 24, D_VIT, pp + "3.weight", 1, 1, 0, 0, 24, 24, D_VIT, E->a(E->L3), E->f(pp + "3.bias"), 0, 0);
-      tap("l3", E->a(E->L3), 24, 24, D_VIT);
+      conv(R, gh, gw, D_VIT, pp + "3.weight", 1, 1, 0, 0, gh, gw, D_VIT, E->a(E->L3), E->f(pp + "3.bias"), 0, 0);
+      tap("l3", E->a(E->L3), gh, gw, D_VIT);
     } else {
-      conv(R, 24, 24, D_VIT, pp + "3.weight", 1, 1, 0, 0, 24, 24, D_VIT, E->a(E->T4), E->f(pp + "3.bias"), 0, 0);
-      conv(E->a(E->T4), 24, 24, D_VIT, pp + "4.weight", 3, 2, 1, 1, 12, 12, D_VIT, E->a(E->L4), E->f(pp + "4.bias"), 0, 0);
-      tap("l4", E->a(E->L4), 12, 12, D_VIT);
+      conv(R, gh, gw, D_VIT, pp + "3.weight", 1, 1, 0, 0, gh, gw, D_VIT, E->a(E->T4), E->f(pp + "3.bias"), 0, 0);
+      conv(E->a(E->T4), gh, gw, D_VIT, pp + "4.weight", 3, 2, 1, 1, h32, w32, D_VIT, E->a(E->L4), E->f(pp + "4.bias"), 0, 0);
+      tap("l4", E->a(E->L4), h32, w32, D_VIT);
     }
   };
 
@@ -571,9 +590,9 @@ int Run::forward(const float* x, float* y) {
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
     chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
     dense(E->a(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, E->a(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0);
-    chk(launch_attention(dt, E->a(E->QKV), E->a(E->AO), B, S_TOK, N_HEADS, E->pl, st), "attention", 1);
-    E->exec_macs += 2.0 * N_HEADS * (double)S_TOK * S_TOK * 64;
-    E->cat_macs[1] += 2.0 * N_HEADS * (double)S_TOK * S_TOK * 64;
+    chk(launch_attention(dt, E->a(E->QKV), E->a(E->AO), B, S, N_HEADS, E->pl, st), "attention", 1);
+    E->exec_macs += 2.0 * N_HEADS * (double)S * S * 64;
+    E->cat_macs[1] += 2.0 * N_HEADS * (double)S * S * 64;
     dense(E->a(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1);
     chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln2", 2);
     dense(E->a(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, E->a(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0);
@@ -590,13 +609,14 @@ int Run::forward(const float* x, float* y) {
 
   // ---- scratch.layerN_rn (3x3, no bias) ---------------------------------------------------
   const void* rn_in[4] = {E->a(E->S[0]), E->a(E->S[1]), E->a(E->L3), E->a(E->L4)};
-  const int rn_h[4] = {96, 48, 24, 12};
+  const int rn_h[4] = {h4, Hi / 8, gh, h32};
+  const int rn_w[4] = {w4, Wi / 8, gw, w32};
   const int rn_c[4] = {256, 512, 768, 768};
   const char* rn_names[4] = {"l1_rn", "l2_rn", "l3_rn", "l4_rn"};
   for (int i = 0; i < 4; ++i) {
-    conv(rn_in[i], rn_h[i], rn_h[i], rn_c[i], "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
-         rn_h[i], FEAT, E->a(E->lrn[i]), nullptr, 0, 0);
-    tap(rn_names[i], E->a(E->lrn[i]), rn_h[i], rn_h[i], FEAT);
+    conv(rn_in[i], rn_h[i], rn_w[i], rn_c[i], "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
+         rn_w[i], FEAT, E->a(E->lrn[i]), nullptr, 0, 0);
+    tap(rn_names[i], E->a(E->lrn[i]), rn_h[i], rn_w[i], FEAT);
   }
 
   // ---- RefineNet fusion 4 -> 1 (blocks.py:320-341).  out_conv (1x1) is applied BEFORE the x2
@@ -606,32 +626,32 @@ int Run::forward(const float* x, float* y) {
   const char* p_names[4] = {"p1", "p2", "p3", "p4"};
   for (int i = 4; i >= 1; --i) {
     const std::string p = "scratch.refinenet" + std::to_string(i) + ".";
-    const int h = rn_h[i - 1];
+    const int h = rn_h[i - 1], w = rn_w[i - 1];
     const void* sum;
     if (i == 4) {
       sum = E->a(E->lrn[3]);
     } else {
-      rcu(p + "resConfUnit1.", E->a(E->lrn[i - 1]), h, E->a(E->tA), E->a(E->tB), path);  // tB = path + RCU1(lrn)
+      rcu(p + "resConfUnit1.", E->a(E->lrn[i - 1]), h, w, E->a(E->tA), E->a(E->tB), path);  // tB = path + RCU1(lrn)
       sum = E->a(E->tB);
     }
-    rcu(p + "resConfUnit2.", sum, h, E->a(E->tA), E->a(E->tC), nullptr);
-    conv(E->a(E->tC), h, h, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, h, FEAT, E->a(E->tA), E->f(p + "out_conv.bias"), 0, 0);
-    chk(launch_upsample2x(dt, E->a(E->tA), E->a(E->P[i - 1]), B, h, h, FEAT, E->pl, st), "fusion.up");
+    rcu(p + "resConfUnit2.", sum, h, w, E->a(E->tA), E->a(E->tC), nullptr);
+    conv(E->a(E->tC), h, w, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, w, FEAT, E->a(E->tA), E->f(p + "out_conv.bias"), 0, 0);
+    chk(launch_upsample2x(dt, E->a(E->tA), E->a(E->P[i - 1]), B, h, w, FEAT, E->pl, st), "fusion.up");
     path = E->a(E->P[i - 1]);
-    tap(p_names[i - 1], path, 2 * h, 2 * h, FEAT);
+    tap(p_names[i - 1], path, 2 * h, 2 * w, FEAT);
   }
 
   // ---- head (dpt_depth.py:91-99) ----------------------------------------------------------
   const std::string oc = "scratch.output_conv.";
-  conv(path, 192, 192, FEAT, oc + "0.weight", 3, 1, 1, 1, 192, 192, 128, E->a(E->H0), E->f(oc + "0.bias"), 0, 0);
-  tap("h0", E->a(E->H0), 192, 192, 128);
-  chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, 192, 192, 128, E->pl, st), "head.up");
-  conv(E->a(E->H0U), 384, 384, 128, oc + "2.weight", 3, 1, 1, 1, 384, 384, 32, E->a(E->H1), E->f(oc + "2.bias"), 1, 0);
-  tap("h1", E->a(E->H1), 384, 384, 32);
-  chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), y, B, IMG * IMG, E->cfg.num_channels,
+  conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, E->a(E->H0), E->f(oc + "0.bias"), 0, 0);
+  tap("h0", E->a(E->H0), h2, w2, 128);
+  chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
+  conv(E->a(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, E->a(E->H1), E->f(oc + "2.bias"), 1, 0);
+  tap("h1", E->a(E->H1), Hi, Wi, 32);
+  chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), y, B, Hi * Wi, E->cfg.num_channels,
                       E->cfg.non_negative, E->pl, st),
       "head.out");
-  E->exec_macs += 147456.0 * 32 * E->cfg.num_channels;
+  E->exec_macs += (double)Hi * Wi * 32 * E->cfg.num_channels;
   E->last_batch = B;
   if (err != hipSuccess) return E->fail(DPTX_E_HIP, std::string("launch failed at ") + where + ": " + hipGetErrorString(err));
   return DPTX_OK;
@@ -660,6 +680,9 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   *out = nullptr;
   // max_batch <= 48: the largest activation (up-sampled head input, 37.7 MB/image) must stay below the 2 GB that a
   // 32-bit buffer offset of the direct-to-LDS loads can address; callers chunk larger batches (model.py does).
+  const int max_h = cfg->max_height ? cfg->max_height : IMG, max_w = cfg->max_width ? cfg->max_width : IMG;
+  if (max_h < 64 || max_w < 64 || max_h % 32 != 0 || max_w % 32 != 0 || max_h > 4096 || max_w > 4096) return DPTX_E_INVALID;
+  if ((long long)cfg->max_batch * max_h * max_w * 256 >= (1ll << 31)) return DPTX_E_INVALID;  // = max_batch <= 56 at 384x384
   if ((cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16 && cfg->dtype != DPTX_DTYPE_BF16X3) ||
       (cfg->ws_form != 0 && cfg->ws_form != 1))
@@ -667,6 +690,9 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   dptx_engine* e = new (std::nothrow) dptx_engine();
   if (!e) return DPTX_E_ALLOC;
   e->cfg = *cfg;
+  e->max_h = max_h;
+  e->max_w = max_w;
+  e->tok_tap_stride = (size_t)cfg->max_batch * ((size_t)max_h * max_w / 256 + 1) * D_VIT;
   e->spec = build_spec(cfg->num_channels);
   size_t off = 0;
   for (size_t i = 0; i < e->spec.size(); ++i) {
@@ -780,20 +806,29 @@ int dptx_enable_taps(dptx_handle h, int on) {
   if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
   if (on && !h->d_tok_taps) {
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
-    HIPCHK(h, hipMalloc((void**)&h->d_tok_taps, (size_t)13 * h->cfg.max_batch * S_TOK * D_VIT * 4));
+    HIPCHK(h, hipMalloc((void**)&h->d_tok_taps, (size_t)13 * h->tok_tap_stride * 4));
   }
   h->taps_on = on != 0;
   return DPTX_OK;
 }
 
 int dptx_forward(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, int32_t batch, void* stream) {
+  return dptx_forward_hw(h, x_dev, x_dtype, y_dev, batch, IMG, IMG, stream);
+}
+
+int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, int32_t batch, int32_t height,
+                    int32_t width, void* stream) {
   if (!h || !x_dev || !y_dev) return DPTX_E_INVALID;
   if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "dptx_forward on a host-only handle");
   if (!h->device_ready) return h->fail(DPTX_E_INVALID, "dptx_forward before weights were finalized/imported");
   if (batch < 1 || batch > h->cfg.max_batch) return h->fail(DPTX_E_INVALID, "batch out of range [1, max_batch]");
   if (x_dtype != DPTX_IO_FP32) return h->fail(DPTX_E_INVALID, "unsupported x_dtype");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  Run run{h, batch, (hipStream_t)stream, h->cfg.dtype};
+  if (height < 64 || width < 64 || height % 32 != 0 || width % 32 != 0)
+    return h->fail(DPTX_E_INVALID, "input height/width must be multiples of 32, >= 64");
+  if ((long long)height * width > (long long)h->max_h * h->max_w)
+    return h->fail(DPTX_E_INVALID, "input larger than the engine was planned for (dptx_config.max_height/max_width)");
+  Run run{h, batch, (hipStream_t)stream, h->cfg.dtype, height, width};
   return run.forward((const float*)x_dev, (float*)y_dev);
 }
 

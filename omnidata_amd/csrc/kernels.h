@@ -77,6 +77,7 @@ hipError_t launch_head_out(int mode, const void* X, const float* w, const float*
                            int Cout, int relu, Planes pl, hipStream_t stream);
 
 // X[b*577] = cls + pos[0]  (fp32 token stream)
+hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, int gw, int C, hipStream_t stream);
 hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, int S, int C, hipStream_t stream);
 
 // out[b][n] = bias[n] + sum_k x[b*x_stride + k] * W[n*ldw + w_off + k]   (x fp32, W 16-bit, out fp32)

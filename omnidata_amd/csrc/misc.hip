@@ -95,6 +95,31 @@ hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------- pos_embed resize
+// vit.py:102-116 _resize_pos_embed: the 24x24 grid part of pos_embed is resampled to (gh, gw) with
+// F.interpolate(mode="bilinear", align_corners=False); the cls row is copied.  ATen's fp32 index math:
+// src = max((dst + 0.5) * (in / out) - 0.5, 0); i0 = int(src); i1 = i0 + (i0 < in - 1); l1 = src - i0.
+__global__ __launch_bounds__(256) void pos_resize_kernel(const float* __restrict__ src, float* __restrict__ dst, int g_old,
+                                                         int gh, int gw, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (gh * gw + 1) * C) return;
+  const int c = i % C, t = i / C;
+  if (t == 0) { dst[i] = src[c]; return; }
+  const int oy = (t - 1) / gw, ox = (t - 1) - oy * gw;
+  const float ry = (float)g_old / (float)gh, rx = (float)g_old / (float)gw;
+  const float sy = fmaxf(((float)oy + 0.5f) * ry - 0.5f, 0.f), sx = fmaxf(((float)ox + 0.5f) * rx - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < g_old - 1 ? 1 : 0), x1 = x0 + (x0 < g_old - 1 ? 1 : 0);
+  const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const float* g = src + C + c;
+  dst[i] = ly0 * (lx0 * g[(y0 * g_old + x0) * C] + lx1 * g[(y0 * g_old + x1) * C]) +
+           ly1 * (lx0 * g[(y1 * g_old + x0) * C] + lx1 * g[(y1 * g_old + x1) * C]);
+}
+hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, int gw, int C, hipStream_t stream) {
+  hipLaunchKernelGGL(pos_resize_kernel, dim3(((gh * gw + 1) * C + 255) / 256), dim3(256), 0, stream, src, dst, g_old, gh, gw, C);
+  return hipGetLastError();
+}
+
 // ----------------------------------------------------- cls half of ProjectReadout (vit.py:44-47)
 // cat(tok, cls) @ W^T = tok @ W[:, :768]^T + cls @ W[:, 768:]^T : the second term is one
 // vector per image, computed here and consumed as a per-image bias by the token GEMM.

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
   const int Ho = H >> 1, Wo = W >> 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int tiles_x = Wo / 64;
+  const int tiles_x = (Wo + 63) / 64;   // the last column tile may be partial (W any multiple of 8)
   const int ox0 = (blockIdx.x % tiles_x) * 64, oy0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.y;
   const int iy0 = 2 * oy0 - pad_t, ix0 = 2 * ox0 - pad_l;
 
@@ -109,15 +109,15 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
     float v[8];
     const float4 a0 = *(const float4*)(ct + p * CT_PITCH + cn * 8), a1 = *(const float4*)(ct + p * CT_PITCH + cn * 8 + 4);
     v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-    store8f<DT, PL>(y + (((long long)b * Ho + oy0 + r) * Wo + ox0 + c) * 64 + cn * 8, act_plane, v);
+    if (ox0 + c < Wo) store8f<DT, PL>(y + (((long long)b * Ho + oy0 + r) * Wo + ox0 + c) * 64 + cn * 8, act_plane, v);
   }
 }
 
 hipError_t launch_stem_conv(int mode, const float* x, const void* Wt, void* y, int B, int H, int W, Planes pl, hipStream_t stream) {
   const int Ho = H / 2, Wo = W / 2;
-  if (H % 8 != 0 || W % 128 != 0) return hipErrorInvalidValue;
+  if (H % 8 != 0 || W % 8 != 0) return hipErrorInvalidValue;
   const int pt = max((Ho - 1) * 2 + 7 - H, 0) / 2, plft = max((Wo - 1) * 2 + 7 - W, 0) / 2;
-  dim3 grid((Wo / 64) * (Ho / 4), B);
+  dim3 grid(((Wo + 63) / 64) * (Ho / 4), B);
   const size_t smem = 256 * 68 * 4;  // C tile (69.6 KB) aliases the patch
   DPTX_DISPATCH_MODE(mode, {
     auto k = stem_conv_kernel<DT, PL>;

@@ -20,7 +20,8 @@ ERRORS = {0: "ok", -1: "invalid argument / call order", -2: "state_dict key erro
 class DptxConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32),
                 ("device_id", C.c_int32), ("non_negative", C.c_int32), ("ws_form", C.c_int32),
-                ("ws_eps", C.c_float), ("reserved", C.c_int32 * 8)]
+                ("ws_eps", C.c_float), ("max_height", C.c_int32), ("max_width", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 # (name, restype, argtypes) for every symbol declared in include/dptx.h
@@ -37,6 +38,7 @@ ABI = [
     ("dptx_import_packed_device", C.c_int, [_vp, _vp, _sz, _vp]),
     ("dptx_workspace_bytes", _sz, [_vp]),
     ("dptx_forward", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    ("dptx_forward_hw", C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_tap", C.c_int, [_vp, C.c_char_p, _vp, _sz, _i64p]),
     ("dptx_enable_taps", C.c_int, [_vp, C.c_int]),
     ("dptx_forward_info", C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -90,13 +92,15 @@ class Engine:
     """One dptx handle: packed weights + activation arena on one GPU (or host-only packing)."""
 
     def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "bf16",
-                 device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8):
+                 device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8,
+                 max_hw: Tuple[int, int] = (384, 384)):
         self.lib = load_library()
         cfg = DptxConfig()
         self.lib.dptx_default_config(C.byref(cfg))
         cfg.num_channels, cfg.max_batch, cfg.dtype = num_channels, max_batch, DTYPES[dtype]
         cfg.device_id = -1 if device_id is None else int(device_id)
         cfg.non_negative, cfg.ws_form, cfg.ws_eps = int(non_negative), ws_form, ws_eps
+        cfg.max_height, cfg.max_width = int(max_hw[0]), int(max_hw[1])
         self.cfg = cfg
         self.dtype = dtype
         self.h = _vp()
@@ -157,13 +161,13 @@ class Engine:
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("dptx forward needs a CUDA(HIP) tensor; there is no CPU fallback")
-        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != 384 or x.shape[3] != 384:
-            raise ValueError(f"expected [B,3,384,384], got {tuple(x.shape)}")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32 (384x384 is the trained size), got {tuple(x.shape)}")
         x = x.contiguous().float()
-        B = x.shape[0]
+        B, _, H, W = x.shape
         if out is None:
-            out = torch.empty(B, self.cfg.num_channels, 384, 384, dtype=torch.float32, device=x.device)
-        self._check(self.lib.dptx_forward(self.h, x.data_ptr(), 0, out.data_ptr(), B, _stream()), "forward")
+            out = torch.empty(B, self.cfg.num_channels, H, W, dtype=torch.float32, device=x.device)
+        self._check(self.lib.dptx_forward_hw(self.h, x.data_ptr(), 0, out.data_ptr(), B, H, W, _stream()), "forward")
         return out
 
     def enable_taps(self, on: bool = True):

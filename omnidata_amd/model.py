@@ -56,6 +56,7 @@ class DPTDepthModel(BaseModel):
         self.channels_last = channels_last  # accepted and, as in the reference (dpt_depth.py:68-69), a no-op
         self.engine_dtype = dtype
         self.max_batch = max(1, min(int(max_batch), 48))  # engine limit; larger batches are chunked in forward()
+        self.max_hw = (384, 384)  # arena is planned for this input size; grows on demand (forward_flex, vit.py:119)
         init = random_state_dict(init_seed, num_channels)
         for key, shape in state_dict_spec(num_channels).items():
             *mods, leaf = key.split(".")
@@ -84,15 +85,19 @@ class DPTDepthModel(BaseModel):
 
     def _get_engine(self, device: torch.device) -> Engine:
         key = (device.index if device.index is not None else torch.cuda.current_device(),
-               self._weights_version, self.engine_dtype, self.max_batch)
+               self._weights_version, self.engine_dtype, self._chunk(), self.max_hw)
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
-            eng = Engine(num_channels=self.num_channels, max_batch=self.max_batch, dtype=self.engine_dtype,
-                         device_id=key[0], non_negative=self.non_negative)
+            eng = Engine(num_channels=self.num_channels, max_batch=self._chunk(), dtype=self.engine_dtype,
+                         device_id=key[0], non_negative=self.non_negative, max_hw=self.max_hw)
             eng.load_state_dict(super().state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine
+
+    def _chunk(self) -> int:
+        """Images per engine call: every activation must stay below 2 GB (32-bit buffer offsets, include/dptx.h)."""
+        return max(1, min(self.max_batch, ((1 << 31) - 1) // (self.max_hw[0] * self.max_hw[1] * 256)))
 
     @property
     def engine(self) -> Optional[Engine]:
@@ -101,21 +106,26 @@ class DPTDepthModel(BaseModel):
     def adopt_engine(self, engine: Engine, device_index: int):
         """Use an engine whose packed weights arrived by broadcast (multi-GPU start-up)."""
         self._engine = engine
-        self._engine_key = (device_index, self._weights_version, self.engine_dtype, self.max_batch)
+        self._engine_key = (device_index, self._weights_version, self.engine_dtype, self._chunk(), self.max_hw)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("omnidata_amd.DPTDepthModel runs only on an AMD GPU (HIP); got a CPU tensor. "
                                "There is no CPU fallback -- use the reference implementation on CPU.")
+        if x.dim() != 4 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32, got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        if H * W > self.max_hw[0] * self.max_hw[1]:
+            self.max_hw = (H, W)  # re-plans the arena (and re-packs the weights) once for the larger size
         eng = self._get_engine(x.device)
-        B = x.shape[0]
-        if B <= self.max_batch:
+        step = self._chunk()
+        if B <= step:
             y = eng.forward(x)
         else:
-            y = torch.empty(B, self.num_channels, 384, 384, dtype=torch.float32, device=x.device)
-            for i in range(0, B, self.max_batch):
-                eng.forward(x[i:i + self.max_batch], out=y[i:i + self.max_batch])
+            y = torch.empty(B, self.num_channels, H, W, dtype=torch.float32, device=x.device)
+            for i in range(0, B, step):
+                eng.forward(x[i:i + step], out=y[i:i + step])
         return y.squeeze(dim=1)  # dpt_depth.py:106-107
 
 

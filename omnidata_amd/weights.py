@@ -189,12 +189,13 @@ def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     return OrderedDict((k, v.detach().float().contiguous()) for k, v in sd.items())
 
 
-def synthetic_input(seed: int, batch: int, task: str = "normal", size: int = 384) -> torch.Tensor:
+def synthetic_input(seed: int, batch: int, task: str = "normal", size=384) -> torch.Tensor:
     """Seeded synthetic image batch in the reference's input convention:
     normal: [0,1] (demo.py:74-76); depth: [-1,1] (demo.py:92-95 Normalize(0.5,0.5))."""
     g = torch.Generator(device="cpu")
     g.manual_seed(7919 * int(seed) + 11)
-    x = torch.rand(batch, 3, size, size, generator=g, dtype=torch.float32)
+    h, w = (size, size) if isinstance(size, int) else size
+    x = torch.rand(batch, 3, h, w, generator=g, dtype=torch.float32)
     if task == "depth":
         x = 2.0 * x - 1.0
     return x

@@ -33,6 +33,8 @@ from omnidata_amd.weights import random_state_dict, state_dict_spec, synthetic_i
 GOLDEN_TAPS = ("stem", "s0", "s1", "s2", "tok0", "blk0", "blk8", "blk11", "l3", "l4",
                "l1_rn", "l4_rn", "p4", "p3", "p2", "p1", "h0", "h1", "pre")
 CASES = [("normal", 3, 0, 1), ("normal", 3, 1, 2), ("depth", 1, 0, 1), ("depth", 1, 2, 1)]
+# inputs that are not 384x384 exercise forward_flex's pos_embed resize (vit.py:102-125); written as flex_*.npz
+FLEX_CASES = [("normal", 3, 3, 1, (256, 320)), ("depth", 1, 4, 2, (448, 288))]
 
 
 def subsample(t: torch.Tensor) -> np.ndarray:
@@ -60,7 +62,9 @@ def main():
 
     torch.set_num_threads(os.cpu_count())
     worst = 0.0
-    for task, C, seed, B in CASES:
+    for case in CASES + FLEX_CASES:
+        task, C, seed, B = case[:4]
+        H, W = case[4] if len(case) > 4 else (384, 384)
         model = DPTDepthModel(backbone="vitb_rn50_384", num_channels=C).eval()
         ref_sd = model.state_dict()
         spec = state_dict_spec(C)
@@ -70,7 +74,7 @@ def main():
             assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
         sd = random_state_dict(seed, C)
         model.load_state_dict(sd, strict=True)
-        x = synthetic_input(seed, B, task)
+        x = synthetic_input(seed, B, task, (H, W))
         with torch.no_grad():
             y_ref = model(x)
         # stage taps of the reference run: hooks dict + re-run pieces through modules
@@ -83,23 +87,25 @@ def main():
         d_b8 = (acts["3"] - taps["blk8"]).abs().max().item()
         d_b11 = (acts["4"] - taps["blk11"]).abs().max().item()
         worst = max(worst, d_out)
-        print(f"[{task} seed={seed} B={B}] ref-vs-oracle max|d|: out={d_out:.3e} hook1={d_l1:.3e} "
+        print(f"[{task} seed={seed} B={B} {H}x{W}] ref-vs-oracle max|d|: out={d_out:.3e} hook1={d_l1:.3e} "
               f"hook2={d_l2:.3e} blk8={d_b8:.3e} blk11={d_b11:.3e}; out mean={y_ref.mean():.4f} "
               f"std={y_ref.std():.4f} min={y_ref.min():.4f} max={y_ref.max():.4f} "
               f"frac0={(y_ref == 0).float().mean():.4f} frac>1={(y_ref > 1).float().mean():.4f}")
         for name in ("s0", "s2", "tok0", "blk11", "l3", "l4", "p4", "p1", "h0", "h1", "pre"):
             t = taps[name]
             print(f"    tap {name:6s} shape={tuple(t.shape)} mean={t.mean():+.3f} std={t.std():.3f} absmax={t.abs().max():.2f}")
-        assert y_ref.shape == ((B, 3, 384, 384) if C == 3 else (B, 384, 384)), y_ref.shape
+        assert y_ref.shape == ((B, 3, H, W) if C == 3 else (B, H, W)), y_ref.shape
         assert d_out < 2e-4, d_out
         if not args.no_write:
             out = {"task": task, "num_channels": C, "seed": seed, "batch": B,
                    "out_sub": subsample(y_ref), "out_stats": stats(y_ref),
-                   "out_row": y_ref.reshape(B, -1, 384, 384)[0, 0, 191].numpy().astype(np.float32)}
+                   "height": H, "width": W,
+                   "out_row": y_ref.reshape(B, -1, H, W)[0, 0, H // 2 - 1].numpy().astype(np.float32)}
             for name in GOLDEN_TAPS:
                 out["tap_" + name] = subsample(taps[name])
                 out["stat_" + name] = stats(taps[name])
-            path = os.path.join(ROOT, "tests", "golden", f"dpt_{task}_seed{seed}.npz")
+            fname = f"dpt_{task}_seed{seed}.npz" if (H, W) == (384, 384) else f"flex_{task}_seed{seed}_{H}x{W}.npz"
+            path = os.path.join(ROOT, "tests", "golden", fname)
             np.savez_compressed(path, **out)
             print("    wrote", path, os.path.getsize(path), "bytes")
     print("worst ref-vs-oracle output difference:", worst)

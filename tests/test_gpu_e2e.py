@@ -139,7 +139,7 @@ def test_input_contract_errors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(torch.zeros(1, 3, 384, 384))
     with pytest.raises(ValueError):
-        model(torch.zeros(1, 3, 256, 256, device=DEV))
+        model(torch.zeros(1, 3, 250, 256, device=DEV))  # not a multiple of 32 (tests/test_gpu_flex.py covers other sizes)
     y = model(torch.zeros(1, 3, 384, 384, device=DEV))
     assert y.shape == (1, 384, 384)
     n, alg, exe = model.engine.info()

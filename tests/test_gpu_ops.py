@@ -155,7 +155,7 @@ def test_upsample2x_align_corners(dtype, B, H, C):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,H,W", [(2, 384, 384), (1, 64, 128), (3, 96, 256)])
+@pytest.mark.parametrize("B,H,W", [(2, 384, 384), (1, 64, 128), (3, 96, 256), (2, 256, 320), (1, 96, 160), (1, 64, 96)])
 def test_fused_stem_conv(dtype, B, H, W):
     """7x7 stride-2 TF-SAME conv straight from the NCHW fp32 image (no im2col)."""
     lib = load_library()

@@ -12,23 +12,25 @@ from oracle.dpt_oracle import dpt_forward, ssi_align, mean_angular_error_deg
 from oracle.validate_vs_reference import GOLDEN_TAPS, stats, subsample
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dpt_*.npz")))
+GOLDEN += sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "flex_*.npz")))  # non-384 inputs
 
 
 def test_golden_files_present():
-    assert len(GOLDEN) >= 4
+    assert len(GOLDEN) >= 6
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 def test_oracle_matches_reference_golden(path):
     g = np.load(path)
     task, C, seed, B = str(g["task"]), int(g["num_channels"]), int(g["seed"]), int(g["batch"])
+    H, W = (int(g["height"]), int(g["width"])) if "height" in g else (384, 384)
     torch.set_num_threads(os.cpu_count())
     taps = {}
-    y = dpt_forward(random_state_dict(seed, C), synthetic_input(seed, B, task), taps)
-    assert tuple(y.shape) == ((B, 3, 384, 384) if C == 3 else (B, 384, 384))
+    y = dpt_forward(random_state_dict(seed, C), synthetic_input(seed, B, task, (H, W)), taps)
+    assert tuple(y.shape) == ((B, 3, H, W) if C == 3 else (B, H, W))
     # fp32 oracle vs fp32 reference: same ops, so only thread-count reassociation noise
     np.testing.assert_allclose(subsample(y), g["out_sub"], atol=2e-5, rtol=0)
-    np.testing.assert_allclose(y.reshape(B, -1, 384, 384)[0, 0, 191].numpy(), g["out_row"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(y.reshape(B, -1, H, W)[0, 0, H // 2 - 1].numpy(), g["out_row"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(stats(y)[:3], g["out_stats"][:3], rtol=1e-4, atol=1e-5)
     for name in GOLDEN_TAPS:
         ref = g["tap_" + name]
