@@ -33,7 +33,7 @@ namespace dptx {
 constexpr int BK = 64;
 
 // ----------------------------------------------------------------------------- shared pieces
-template <int DT, int TM, int TN, bool RELU_A, int PL = 1>
+template <int DT, int TM, int TN, bool RELU_A, int PL = 1, int HK = BK / 16>
 __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_lo, int b_lo, int wm, int wn, int lr, int lh,
                                          f32x16_t (&acc)[TM][TN]) {
   // a_lo / b_lo: byte distance of the lo-plane tiles inside the stage (PL == 2)
@@ -41,31 +41,37 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
     // all fragment reads of the k-tile are issued up front (16 ds_read_b128 in flight for a 64x64 wave tile,
     // 64 VGPRs) and the MFMAs consume them behind counted lgkmcnt waits: the LDS latency is paid once per
     // k-tile instead of once per k-step
-    u32x4_t af[BK / 16][TM], bf[BK / 16][TN];
+    // (HK k-steps per group: 4 = the whole k-tile for 64x64 wave tiles; 2 for the 128x64 wave tile of the
+    // 256x256 block, whose 128 accumulator registers leave room for 48 fragment registers, not 96)
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int chunk = 2 * ks + lh;
+    for (int g = 0; g < BK / 16; g += HK) {
+      u32x4_t af[HK][TM], bf[HK][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (TM * 32) + i * 32 + lr;
-        af[ks][i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      for (int ks = 0; ks < HK; ++ks) {
+        const int chunk = 2 * (g + ks) + lh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * (TM * 32) + i * 32 + lr;
+          af[ks][i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wn * (TN * 32) + j * 32 + lr;
+          bf[ks][j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler otherwise sinks them
+                                          // back to one k-step of look-ahead to save registers)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * (TN * 32) + j * 32 + lr;
-        bf[ks][j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      for (int ks = 0; ks < HK; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (RELU_A) af[ks][i] = relu8(af[ks][i]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = T16<DT>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+        }
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler otherwise sinks them
-                                        // back to one k-step of look-ahead to save registers)
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (RELU_A) af[ks][i] = relu8(af[ks][i]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = T16<DT>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
-      }
+      if (HK != BK / 16) __builtin_amdgcn_sched_barrier(0);
     }
     return;
   }
@@ -105,21 +111,31 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
   }
 }
 
-template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256>
+// SLABS == 1: the whole BM x BN tile goes through LDS at once.  SLABS == TM (256x256 block: the fp32 tile would be
+// 266 KB): TM passes, pass s carries the s-th 32-row MFMA tile of every wave -- LDS row q = (wave row)*32 + r is tile
+// row (q/32)*(TM*32) + s*32 + q%32.
+template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                          int tid, f32x16_t (&acc)[TM][TN]) {
+  static_assert(SLABS == 1 || SLABS == TM, "one slab, or one per MFMA row tile");
   constexpr int CT_PITCH = BN + 4;  // floats
+  constexpr int CT_ROWS = BM / SLABS;
   float* ct = (float*)smem;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+ for (int s = 0; s < SLABS; ++s) {
+  if (s > 0) __syncthreads();  // the previous slab has been read out
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (SLABS != 1 && i != s) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ml = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int ml = (SLABS == 1 ? wm * (TM * 32) + i * 32 : wm * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int nl = wn * (TN * 32) + j * 32 + lr;
         ct[ml * CT_PITCH + nl] = acc[i][j][r];
       }
+  }
   __syncthreads();
 
   constexpr int NCH = BN / 8;     // 8-column chunks per tile row
@@ -136,8 +152,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
     bias_c[4] = b1.x; bias_c[5] = b1.y; bias_c[6] = b1.z; bias_c[7] = b1.w;
   }
 #pragma unroll 2
-  for (int row = rr; row < BM; row += RPP) {
-    const int m = m0 + row;
+  for (int row = rr; row < CT_ROWS; row += RPP) {
+    const int m = m0 + (SLABS == 1 ? row : (row >> 5) * (TM * 32) + s * 32 + (row & 31));
     if (m >= p.M) break;
     const int img = m / p.c_rpi;
     const int pp = m - img * p.c_rpi;
@@ -201,17 +217,23 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       store8f<DT, PL>((uint16_t*)p.C + coff, p.planes.act, v);
     }
   }
+ }
 }
 
 // ------------------------------------------------------------------- direct-to-LDS kernel
 constexpr unsigned OOB = 0x80000000u;  // >= any buffer size we bind (a_bytes < 2^31): reads as zero
 
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A, int PL>
-__global__ __launch_bounds__(256, PL == 2 ? 1 : 2) void gemm_glds_kernel(const GemmParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_glds_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer/LDS-DMA builtins exist only in the device pass
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  constexpr int NT = 64 * WAVES_M * WAVES_N;  // 256 threads (2 blocks/CU), or 512 for the 256x256 tile (1 block/CU)
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
   constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+  constexpr int ROWS_PP = NT / 8;                // tile rows one loader pass covers (8 threads x 16 B per 128-B row)
+  constexpr int PASS_BYTES = ROWS_PP * 128;
+  constexpr int A_PASSES = BM / ROWS_PP, B_PASSES = BN / ROWS_PP;
+  constexpr int HK = (TM * TN > 4) ? 2 : BK / 16;
+  constexpr int SLABS = (BM * (BN + 4) * 4 > 160 * 1024) ? TM : 1;
   // stage image: [A hi][A lo (PL==2)][W hi][W lo (PL==2)]
   constexpr int A_LO = BM * 128, B_BASE = PL * BM * 128, B_LO = BN * 128;
   constexpr int STAGE_BYTES = PL * (BM + BN) * 128;
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(256, PL == 2 ? 1 : 2) void gemm_glds_kernel(const G
   unsigned a_off[A_PASSES];  // byte offset of (img, iy0, ix0, source chunk), mod 2^32
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + r0 + 32 * i;
+    const int m = m0 + r0 + ROWS_PP * i;
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
     const int img = mm / p.a_rpi;
@@ -261,7 +283,7 @@ __global__ __launch_bounds__(256, PL == 2 ? 1 : 2) void gemm_glds_kernel(const G
   }
   unsigned w_off[B_PASSES];
 #pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2);
+  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + ROWS_PP * j) * p.ldw + sc * 8) * 2);
 
   const int w_bytes = (int)((long long)p.N * p.ldw * 2);
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
@@ -283,17 +305,17 @@ __global__ __launch_bounds__(256, PL == 2 ? 1 : 2) void gemm_glds_kernel(const G
       const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
       const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
       const unsigned vo = valid ? a_off[i] + tap_ : OOB;                                                           \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(sa_ + i * 4096), 16, vo, 0, \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(sa_ + i * PASS_BYTES), 16, vo, 0, \
                                                0, 0);                                                              \
       if (PL == 2)                                                                                                 \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcAl, (__attribute__((address_space(3))) void*)(sa_ + A_LO + i * 4096), \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcAl, (__attribute__((address_space(3))) void*)(sa_ + A_LO + i * PASS_BYTES), \
                                                  16, vo, 0, 0, 0);                                                 \
     }                                                                                                              \
     _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) {                                                         \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(sb_ + j * 4096), 16,        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(sb_ + j * PASS_BYTES), 16,   \
                                                w_off[j] + (unsigned)((K0) * 2), 0, 0, 0);                          \
       if (PL == 2)                                                                                                 \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcWl, (__attribute__((address_space(3))) void*)(sb_ + B_LO + j * 4096), \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcWl, (__attribute__((address_space(3))) void*)(sb_ + B_LO + j * PASS_BYTES), \
                                                  16, w_off[j] + (unsigned)((K0) * 2), 0, 0, 0);                    \
     }                                                                                                              \
     c0 += BK;                                                                                                      \
@@ -320,11 +342,11 @@ __global__ __launch_bounds__(256, PL == 2 ? 1 : 2) void gemm_glds_kernel(const G
     __syncthreads();
     if (kt + 1 < nk) DPTX_ISSUE_TILE((kt + 1) & 1, (kt + 1) * BK);
     const char* sa = smem + (kt & 1) * STAGE_BYTES;
-    mma_tile<DT, TM, TN, RELU_A, PL>(sa, sa + B_BASE, A_LO, B_LO, wm, wn, lr, lh, acc);
+    mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, A_LO, B_LO, wm, wn, lr, lh, acc);
   }
 #undef DPTX_ISSUE_TILE
   __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
-  epilogue<DT, BM, BN, TM, TN, PL>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
 }
 
@@ -469,7 +491,8 @@ __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
 template <int BM, int BN, int PL>
 constexpr size_t gemm_smem_bytes() {
   constexpr size_t stage = 2 * (size_t)PL * (BM + BN) * 128;
-  constexpr size_t ct = (size_t)BM * (BN + 4) * 4;
+  constexpr size_t ct_full = (size_t)BM * (BN + 4) * 4;
+  constexpr size_t ct = ct_full > 160 * 1024 ? (size_t)64 * (BN + 4) * 4 : ct_full;  // slab epilogue (2 wave rows x 32)
   return stage > ct ? stage : ct;
 }
 
@@ -531,13 +554,15 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL>;
       static bool done = false;
       if (!done) { set_smem_attr(k, smem); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, q);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     } else {
       auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
       static bool done = false;
       if (!done) { set_smem_attr(k, smem); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, stream, q);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     }
+  } else if constexpr (WM_ * WN_ != 4) {
+    return hipErrorInvalidValue;  // the 8-wave tile exists only on the direct-to-LDS path
   } else if constexpr (PL == 1) {
     constexpr size_t smem1 = gemm_smem_bytes<BM, BN, 1>();
     if (p.a_fp32) {
@@ -559,11 +584,23 @@ template <int DT, int PL>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
   const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
-  {  // DPTX_TILE=12864 / 6464 forces a tile shape (occupancy experiments)
-    static int forced = -1;
-    if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
+  static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (experiments)
+  if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
+  {
     if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
     if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
+  }
+  // 256x256 (8 waves, 1 block/CU): half the DMA issues and 3/4 of the LDS reads per MFMA of the 128x128 tile, but no
+  // second block to hide prologue/epilogue and a coarser tail.  Measured (profiles/r01_gemm_tile256_ab.txt): +3..8 %
+  // on long-K problems whose tile count fills the 256 CUs evenly (fc2, the 3x3 convs at 1/4 resolution), -2..-22 %
+  // elsewhere -- so: K >= 2048 and >= 85 % of the last round of CUs busy.
+  if constexpr (PL == 1) {
+    const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && gemm_variant() != 1;
+    static int min_k = -1;  // DPTX_T256_MINK: shortest K that takes the 256x256 tile (experiments)
+    if (min_k < 0) { const char* t = getenv("DPTX_T256_MINK"); min_k = t ? atoi(t) : 2048; }
+    const long long t256 = m256 * (p.N / 256), rounds = (t256 + 255) / 256;
+    if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= min_k && t256 >= 200 && t256 * 100 >= rounds * 256 * 85)
+      return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
   }
   if (p.N % 128 == 0 && m128 * (p.N / 128) >= 448) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
   if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1>(p, stream);

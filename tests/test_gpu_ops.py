@@ -32,8 +32,9 @@ def test_gemm_plain(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_gemm_epilogues(dtype):
-    M, N, K = 1731, 768, 768
+@pytest.mark.parametrize("M", [1731, 18470])  # 18470 x 768: the 256x256 (8-wave, slab epilogue) tile, ragged last m-tile
+def test_gemm_epilogues(dtype, M):
+    N, K = 768, 768
     A, W = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=4)
     bias = torch.randn(N, device=DEV)
     R16 = rnd(M, N, dtype=dtype, seed=5)
@@ -74,9 +75,10 @@ def conv_ref(X, Wt, bias, stride, pad_t, pad_l, Ho, Wo, a_relu):
     (2, 96, 64, 64, 3, 1, 1, 96, 0, 0, False),     # stage0 conv2 (N=64)
     (1, 40, 128, 32, 3, 1, 1, 40, 0, 1, False),    # head conv 128->32 (+ReLU), N=32 tile
     (5, 12, 768, 256, 3, 1, 1, 12, 0, 0, False),   # layer4_rn (small map, K=6912)
-    (8, 96, 256, 256, 3, 1, 1, 96, 1, 1, False),   # big-M RCU conv1: 8-wave 3-stage kernel, pre-ReLU
-    (8, 96, 256, 128, 3, 1, 1, 96, 0, 0, True),    # big-M, N=128, residual: 8-wave 3-stage kernel
+    (8, 96, 256, 256, 3, 1, 1, 96, 1, 1, False),   # big-M RCU conv1: 256x256 8-wave tile, pre-ReLU
+    (8, 96, 256, 128, 3, 1, 1, 96, 0, 0, True),    # big-M, N=128, residual
     (9, 48, 512, 256, 3, 1, 1, 48, 0, 0, False),   # layer2_rn at batch 9 (M not a multiple of 256)
+    (23, 48, 256, 256, 3, 1, 1, 48, 1, 0, True),   # 256x256 tile, M = 52992 (207 m-tiles), pre-ReLU + residual
 ])
 def test_conv_implicit_gemm(dtype, case):
     B, H, Cin, Cout, k, stride, pad, Ho, a_relu, act, res = case
