@@ -29,8 +29,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_IMAGE = {"normal": 255.25, "depth": 255.23}          # SURVEY.md 8d (algorithmic)
-GEMM_GMAC_PER_IMAGE = {"normal": 121.487, "depth": 121.478}    # A.6: convs + linears (attention excluded)
+# "dual" = BASELINE.json configs[4]: both tasks from one encoder pass, per image (185.29 GMAC)
+GFLOP_PER_IMAGE = {"normal": 255.25, "depth": 255.23, "dual": 370.58}          # SURVEY.md 8d (algorithmic)
+GEMM_GMAC_PER_IMAGE = {"normal": 121.487, "depth": 121.478, "dual": 179.153}  # A.6: convs + linears (attention excluded)
 PEAK_TFLOPS = 2500.0                                           # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
@@ -40,7 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--task", default="normal", choices=["normal", "depth"])
+    ap.add_argument("--task", default="normal", choices=["normal", "depth", "dual"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -72,12 +73,17 @@ def main():
     if world > 1:
         dist.barrier()
     from omnidata_amd.dist import build_replicated_engine
-    from omnidata_amd.weights import random_state_dict, synthetic_input
+    from omnidata_amd.weights import random_dual_state_dict, random_state_dict, synthetic_input
 
-    C = 3 if args.task == "normal" else 1
-    eng = build_replicated_engine(lambda: random_state_dict(0, C), C, args.batch, args.dtype, local_rank)
-    x = synthetic_input(1000 + rank, args.batch, args.task).to(device)
+    dual = args.task == "dual"
+    C = 1 if args.task == "depth" else 3
+    make_sd = (lambda: random_dual_state_dict(0)) if dual else (lambda: random_state_dict(0, C))
+    eng = build_replicated_engine(make_sd, C, args.batch, args.dtype, local_rank, dual=dual)
+    x = synthetic_input(1000 + rank, args.batch, "normal" if dual else args.task).to(device)
     y = torch.empty(args.batch, C, 384, 384, dtype=torch.float32, device=device)
+    if dual:  # one step = one encoder pass + both decoders on the batch
+        y2 = torch.empty(args.batch, 1, 384, 384, dtype=torch.float32, device=device)
+        eng.forward = lambda x_, out=None: eng.forward_dual(x_, out_normal=out, out_depth=y2)
 
     def sync_all():
         if world > 1:
@@ -139,9 +145,11 @@ def main():
     # ---- CPU baseline: the fp32 oracle on this host, bounded sample
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.dpt_oracle import dpt_forward
-        sd = random_state_dict(0, C)
-        xc = synthetic_input(1000, 4, args.task)
+        from oracle.dpt_oracle import dpt_forward, dpt_forward_dual
+        sd = make_sd()
+        if dual:
+            dpt_forward = dpt_forward_dual  # noqa: F811  (the reference forward twice, encoder weights tied)
+        xc = synthetic_input(1000, 4, "normal" if dual else args.task)
         ncpu = os.cpu_count() or 1
         # oneDNN/MKL at batch 4 stop scaling (and then collapse) well before 256 threads: probe a few
         # thread counts on one batch each and keep the fastest for the timed sample
@@ -174,13 +182,14 @@ def main():
         value = total_images / elapsed
         e2e_tflops = value * GFLOP_PER_IMAGE[args.task] / 1e3
         line = {
-            "metric": "images/sec (384x384) DPT-Hybrid surface-normal inference" if args.task == "normal"
-                      else "images/sec (384x384) DPT-Hybrid depth inference",
+            "metric": {"normal": "images/sec (384x384) DPT-Hybrid surface-normal inference",
+                       "depth": "images/sec (384x384) DPT-Hybrid depth inference",
+                       "dual": "images/sec (384x384) DPT-Hybrid dual-task normal+depth, shared encoder"}[args.task],
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic 384x384 inputs resident in HBM; seeded random weights",
             "config": {"workload": f"DPT-Hybrid-384 {args.task}, batch {args.batch}/GPU, {args.dtype}, {world}xMI355X "
-                                   "(BASELINE.json configs[1])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                                   f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"replicas x{world} (no collective in the loop)"},
             "e2e_mfma_frac": round(e2e_tflops / (PEAK_TFLOPS * world), 4),
             "e2e_tflops_algorithmic": round(e2e_tflops, 1),

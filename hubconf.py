@@ -38,3 +38,15 @@ def surface_normal_dpt_hybrid_384(pretrained=True, **kwargs):
 
 def depth_dpt_hybrid_384(pretrained=True, **kwargs):
     return dpt_hybrid_384(pretrained=pretrained, task="depth", **kwargs)
+
+
+def dual_dpt_hybrid_384(pretrained=False, backbone="normal", normal_weights=None, depth_weights=None, **kwargs):
+    """Not in the reference's hub list: normals + depth from ONE encoder pass (omnidata_amd.model.DPTDualTaskModel).
+    With pretrained=True the two v2 checkpoints are read and `backbone` ('normal'|'depth') donates `pretrained.*`."""
+    from omnidata_amd.model import DPTDualTaskModel
+    from omnidata_amd.weights import read_checkpoint
+    if not pretrained and not (normal_weights and depth_weights):
+        return DPTDualTaskModel(**kwargs).eval()
+    n = read_checkpoint(_find_ckpt("normal", normal_weights))
+    d = read_checkpoint(_find_ckpt("depth", depth_weights))
+    return DPTDualTaskModel.from_single_task(n, d, backbone=backbone, **kwargs).eval()

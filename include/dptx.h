@@ -55,7 +55,8 @@ typedef struct dptx_config {
   float   ws_eps;        /* StdConv2dSame eps (timm vit_base_r50_s16: 1e-8)                     */
   int32_t max_height;    /* largest input the arena is planned for; 0 = 384. Multiples of 32,   */
   int32_t max_width;     /*   >= 64, and max_batch*max_height*max_width*256 < 2^31 (see dptx_forward_hw) */
-  int32_t reserved[6];   /* must be zero                                                        */
+  int32_t dual_task;     /* 1: two decoders on one shared encoder (see dptx_forward_dual); needs num_channels = 3 */
+  int32_t reserved[5];   /* must be zero                                                        */
 } dptx_config;
 
 /* Fills *cfg with the reference defaults: C=3, max_batch=32, bf16, device 0, non_negative=1,
@@ -115,6 +116,16 @@ int dptx_forward(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev,
  * dptx_forward(...) == dptx_forward_hw(..., 384, 384, ...). */
 int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev,
                     int32_t batch, int32_t height, int32_t width, void* stream);
+
+/* Dual-task forward (BASELINE.json configs[4]): ONE encoder pass (`pretrained.*`: ResNetV2 stem and
+ * stages, ViT blocks, read-outs, DPT.forward dpt_depth.py:71) feeds TWO decoders -- `scratch.*` (surface normals, 3
+ * channels) and `depth.scratch.*` (depth, 1 channel; same layer names as dpt_depth.py:73-83 behind the "depth." prefix).
+ * 185.29 GMAC per image instead of 2 x 127.62.  This is a composition the reference does not ship (its two checkpoints
+ * are separately fine-tuned full models); parity is defined against the reference forward run twice with `pretrained.*`
+ * tied.  Needs a handle created with dual_task = 1, num_channels = 3; both heads see the same input tensor.
+ *   y_normal_dev [batch,3,height,width], y_depth_dev [batch,1,height,width], NCHW fp32. */
+int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_normal_dev, void* y_depth_dev,
+                      int32_t batch, int32_t height, int32_t width, void* stream);
 
 /* Debug hook for stage-level parity (SURVEY.md A.1 tap names: "stem","s0","s1","s2","tok0",
  * "blk0".."blk11","l3","l4","l1_rn".."l4_rn","p4","p3","p2","p1","h0","h1").  Copies the

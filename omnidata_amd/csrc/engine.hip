@@ -82,7 +82,9 @@ struct Spec {
 void add(std::vector<Spec>& v, const std::string& k, std::vector<int64_t> s, Role r) { v.push_back({k, std::move(s), r}); }
 
 // Mirrors omnidata_amd/weights.py:state_dict_spec (reference key names).
-std::vector<Spec> build_spec(int C) {
+// `dual`: a second decoder (depth, 1 channel) under "depth.scratch.*" next to the normal one (3 channels) under
+// "scratch.*"; both read the one shared encoder "pretrained.*" (SURVEY.md 8d config 5).
+std::vector<Spec> build_spec(int C, bool dual) {
   std::vector<Spec> v;
   const std::string vp = "pretrained.model.";
   add(v, vp + "cls_token", {1, 1, D_VIT}, R_VEC);
@@ -145,26 +147,30 @@ std::vector<Spec> build_spec(int C) {
       add(v, p + "4.bias", {D_VIT}, R_VEC);
     }
   }
-  const int rn_in[4] = {256, 512, 768, 768};
-  for (int i = 1; i <= 4; ++i) add(v, "scratch.layer" + std::to_string(i) + "_rn.weight", {FEAT, rn_in[i - 1], 3, 3}, R_CONV);
-  for (int i = 1; i <= 4; ++i) {
-    const std::string p = "scratch.refinenet" + std::to_string(i) + ".";
-    add(v, p + "out_conv.weight", {FEAT, FEAT, 1, 1}, R_CONV);
-    add(v, p + "out_conv.bias", {FEAT}, R_VEC);
-    for (int u = 1; u <= 2; ++u)
-      for (int c = 1; c <= 2; ++c) {
-        const bool unused = (i == 4 && u == 1);  // blocks.py:329-333: resConfUnit1 needs two inputs
-        const std::string q = p + "resConfUnit" + std::to_string(u) + ".conv" + std::to_string(c) + ".";
-        add(v, q + "weight", {FEAT, FEAT, 3, 3}, unused ? R_UNUSED : R_CONV);
-        add(v, q + "bias", {FEAT}, unused ? R_UNUSED : R_VEC);
-      }
-  }
-  add(v, "scratch.output_conv.0.weight", {FEAT / 2, FEAT, 3, 3}, R_CONV);
-  add(v, "scratch.output_conv.0.bias", {FEAT / 2}, R_VEC);
-  add(v, "scratch.output_conv.2.weight", {32, FEAT / 2, 3, 3}, R_CONV);
-  add(v, "scratch.output_conv.2.bias", {32}, R_VEC);
-  add(v, "scratch.output_conv.4.weight", {C, 32, 1, 1}, R_HEAD4);
-  add(v, "scratch.output_conv.4.bias", {C}, R_VEC);
+  auto decoder = [&](const std::string& pre, int ch) {
+    const int rn_in[4] = {256, 512, 768, 768};
+    for (int i = 1; i <= 4; ++i) add(v, pre + "scratch.layer" + std::to_string(i) + "_rn.weight", {FEAT, rn_in[i - 1], 3, 3}, R_CONV);
+    for (int i = 1; i <= 4; ++i) {
+      const std::string p = pre + "scratch.refinenet" + std::to_string(i) + ".";
+      add(v, p + "out_conv.weight", {FEAT, FEAT, 1, 1}, R_CONV);
+      add(v, p + "out_conv.bias", {FEAT}, R_VEC);
+      for (int u = 1; u <= 2; ++u)
+        for (int c = 1; c <= 2; ++c) {
+          const bool unused = (i == 4 && u == 1);  // blocks.py:329-333: resConfUnit1 needs two inputs
+          const std::string q = p + "resConfUnit" + std::to_string(u) + ".conv" + std::to_string(c) + ".";
+          add(v, q + "weight", {FEAT, FEAT, 3, 3}, unused ? R_UNUSED : R_CONV);
+          add(v, q + "bias", {FEAT}, unused ? R_UNUSED : R_VEC);
+        }
+    }
+    add(v, pre + "scratch.output_conv.0.weight", {FEAT / 2, FEAT, 3, 3}, R_CONV);
+    add(v, pre + "scratch.output_conv.0.bias", {FEAT / 2}, R_VEC);
+    add(v, pre + "scratch.output_conv.2.weight", {32, FEAT / 2, 3, 3}, R_CONV);
+    add(v, pre + "scratch.output_conv.2.bias", {32}, R_VEC);
+    add(v, pre + "scratch.output_conv.4.weight", {ch, 32, 1, 1}, R_HEAD4);
+    add(v, pre + "scratch.output_conv.4.bias", {ch}, R_VEC);
+  };
+  decoder("", dual ? 3 : C);
+  if (dual) decoder("depth.", 1);
   return v;
 }
 
@@ -436,10 +442,10 @@ struct Run {
     conv(tmp, H, W, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, W, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra);
   }
 
-  int forward(const float* x, float* y);
+  int forward(const float* x, float* y, float* y2);
 };
 
-int Run::forward(const float* x, float* y) {
+int Run::forward(const float* x, float* y, float* y2) {
   dptx_engine* E = e;
   E->taps.clear();
   E->launches = 0;
@@ -607,6 +613,9 @@ int Run::forward(const float* x, float* y) {
   }
   // timm's final model.norm is dead compute in the reference (vit.py:153, result discarded :64)
 
+  // one decoder = scratch.* of one task ("" -> scratch.*, "depth." -> depth.scratch.*); the dual-task engine runs two
+  // on the same encoder outputs (S[0], S[1], L3, L4 are not modified by a decoder)
+  auto decode = [&](const std::string& pre, int ch, float* yout) {
   // ---- scratch.layerN_rn (3x3, no bias) ---------------------------------------------------
   const void* rn_in[4] = {E->a(E->S[0]), E->a(E->S[1]), E->a(E->L3), E->a(E->L4)};
   const int rn_h[4] = {h4, Hi / 8, gh, h32};
@@ -614,9 +623,9 @@ int Run::forward(const float* x, float* y) {
   const int rn_c[4] = {256, 512, 768, 768};
   const char* rn_names[4] = {"l1_rn", "l2_rn", "l3_rn", "l4_rn"};
   for (int i = 0; i < 4; ++i) {
-    conv(rn_in[i], rn_h[i], rn_w[i], rn_c[i], "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
+    conv(rn_in[i], rn_h[i], rn_w[i], rn_c[i], pre + "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
          rn_w[i], FEAT, E->a(E->lrn[i]), nullptr, 0, 0);
-    tap(rn_names[i], E->a(E->lrn[i]), rn_h[i], rn_w[i], FEAT);
+    tap((pre + rn_names[i]).c_str(), E->a(E->lrn[i]), rn_h[i], rn_w[i], FEAT);
   }
 
   // ---- RefineNet fusion 4 -> 1 (blocks.py:320-341).  out_conv (1x1) is applied BEFORE the x2
@@ -625,7 +634,7 @@ int Run::forward(const float* x, float* y) {
   const void* path = nullptr;
   const char* p_names[4] = {"p1", "p2", "p3", "p4"};
   for (int i = 4; i >= 1; --i) {
-    const std::string p = "scratch.refinenet" + std::to_string(i) + ".";
+    const std::string p = pre + "scratch.refinenet" + std::to_string(i) + ".";
     const int h = rn_h[i - 1], w = rn_w[i - 1];
     const void* sum;
     if (i == 4) {
@@ -638,20 +647,23 @@ int Run::forward(const float* x, float* y) {
     conv(E->a(E->tC), h, w, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, w, FEAT, E->a(E->tA), E->f(p + "out_conv.bias"), 0, 0);
     chk(launch_upsample2x(dt, E->a(E->tA), E->a(E->P[i - 1]), B, h, w, FEAT, E->pl, st), "fusion.up");
     path = E->a(E->P[i - 1]);
-    tap(p_names[i - 1], path, 2 * h, 2 * w, FEAT);
+    tap((pre + p_names[i - 1]).c_str(), path, 2 * h, 2 * w, FEAT);
   }
 
   // ---- head (dpt_depth.py:91-99) ----------------------------------------------------------
-  const std::string oc = "scratch.output_conv.";
+  const std::string oc = pre + "scratch.output_conv.";
   conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, E->a(E->H0), E->f(oc + "0.bias"), 0, 0);
-  tap("h0", E->a(E->H0), h2, w2, 128);
+  tap((pre + "h0").c_str(), E->a(E->H0), h2, w2, 128);
   chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
   conv(E->a(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, E->a(E->H1), E->f(oc + "2.bias"), 1, 0);
-  tap("h1", E->a(E->H1), Hi, Wi, 32);
-  chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), y, B, Hi * Wi, E->cfg.num_channels,
+  tap((pre + "h1").c_str(), E->a(E->H1), Hi, Wi, 32);
+  chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, B, Hi * Wi, ch,
                       E->cfg.non_negative, E->pl, st),
       "head.out");
-  E->exec_macs += (double)Hi * Wi * 32 * E->cfg.num_channels;
+  E->exec_macs += (double)Hi * Wi * 32 * ch;
+  };
+  decode("", E->cfg.num_channels, y);
+  if (E->cfg.dual_task) decode("depth.", 1, y2);
   E->last_batch = B;
   if (err != hipSuccess) return E->fail(DPTX_E_HIP, std::string("launch failed at ") + where + ": " + hipGetErrorString(err));
   return DPTX_OK;
@@ -683,7 +695,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   const int max_h = cfg->max_height ? cfg->max_height : IMG, max_w = cfg->max_width ? cfg->max_width : IMG;
   if (max_h < 64 || max_w < 64 || max_h % 32 != 0 || max_w % 32 != 0 || max_h > 4096 || max_w > 4096) return DPTX_E_INVALID;
   if ((long long)cfg->max_batch * max_h * max_w * 256 >= (1ll << 31)) return DPTX_E_INVALID;  // = max_batch <= 56 at 384x384
-  if ((cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
+  if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
+      (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16 && cfg->dtype != DPTX_DTYPE_BF16X3) ||
       (cfg->ws_form != 0 && cfg->ws_form != 1))
     return DPTX_E_INVALID;
@@ -693,7 +706,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   e->max_h = max_h;
   e->max_w = max_w;
   e->tok_tap_stride = (size_t)cfg->max_batch * ((size_t)max_h * max_w / 256 + 1) * D_VIT;
-  e->spec = build_spec(cfg->num_channels);
+  e->spec = build_spec(cfg->num_channels, cfg->dual_task != 0);
   size_t off = 0;
   for (size_t i = 0; i < e->spec.size(); ++i) {
     e->spec_index[e->spec[i].key] = i;
@@ -828,8 +841,26 @@ int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_d
     return h->fail(DPTX_E_INVALID, "input height/width must be multiples of 32, >= 64");
   if ((long long)height * width > (long long)h->max_h * h->max_w)
     return h->fail(DPTX_E_INVALID, "input larger than the engine was planned for (dptx_config.max_height/max_width)");
+  if (h->cfg.dual_task) return h->fail(DPTX_E_INVALID, "dual-task handle: call dptx_forward_dual");
   Run run{h, batch, (hipStream_t)stream, h->cfg.dtype, height, width};
-  return run.forward((const float*)x_dev, (float*)y_dev);
+  return run.forward((const float*)x_dev, (float*)y_dev, nullptr);
+}
+
+int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_normal_dev, void* y_depth_dev, int32_t batch,
+                      int32_t height, int32_t width, void* stream) {
+  if (!h || !x_dev || !y_normal_dev || !y_depth_dev) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "dptx_forward_dual on a host-only handle");
+  if (!h->cfg.dual_task) return h->fail(DPTX_E_INVALID, "dptx_forward_dual needs a handle created with dual_task = 1");
+  if (!h->device_ready) return h->fail(DPTX_E_INVALID, "dptx_forward_dual before weights were finalized/imported");
+  if (batch < 1 || batch > h->cfg.max_batch) return h->fail(DPTX_E_INVALID, "batch out of range [1, max_batch]");
+  if (x_dtype != DPTX_IO_FP32) return h->fail(DPTX_E_INVALID, "unsupported x_dtype");
+  if (height < 64 || width < 64 || height % 32 != 0 || width % 32 != 0)
+    return h->fail(DPTX_E_INVALID, "input height/width must be multiples of 32, >= 64");
+  if ((long long)height * width > (long long)h->max_h * h->max_w)
+    return h->fail(DPTX_E_INVALID, "input larger than the engine was planned for (dptx_config.max_height/max_width)");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  Run run{h, batch, (hipStream_t)stream, h->cfg.dtype, height, width};
+  return run.forward((const float*)x_dev, (float*)y_normal_dev, (float*)y_depth_dev);
 }
 
 int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_floats, int64_t shape4[4]) {
@@ -858,7 +889,8 @@ int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_f
 int dptx_forward_info(dptx_handle h, int64_t* launches, double* algorithmic_macs, double* executed_macs) {
   if (!h) return DPTX_E_INVALID;
   if (launches) *launches = h->launches;
-  if (algorithmic_macs) *algorithmic_macs = h->cfg.num_channels == 3 ? 127.624e9 : 127.615e9;
+  if (algorithmic_macs)  // SURVEY.md 8d (dual: 69.96 shared + 2 x 57.67 per image pair)
+    *algorithmic_macs = h->cfg.dual_task ? 185.29e9 : (h->cfg.num_channels == 3 ? 127.624e9 : 127.615e9);
   if (executed_macs) *executed_macs = h->exec_macs;
   return DPTX_OK;
 }

@@ -21,7 +21,7 @@ class DptxConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32),
                 ("device_id", C.c_int32), ("non_negative", C.c_int32), ("ws_form", C.c_int32),
                 ("ws_eps", C.c_float), ("max_height", C.c_int32), ("max_width", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("dual_task", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 # (name, restype, argtypes) for every symbol declared in include/dptx.h
@@ -39,6 +39,7 @@ ABI = [
     ("dptx_workspace_bytes", _sz, [_vp]),
     ("dptx_forward", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
     ("dptx_forward_hw", C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    ("dptx_forward_dual", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_tap", C.c_int, [_vp, C.c_char_p, _vp, _sz, _i64p]),
     ("dptx_enable_taps", C.c_int, [_vp, C.c_int]),
     ("dptx_forward_info", C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -93,7 +94,7 @@ class Engine:
 
     def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "bf16",
                  device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8,
-                 max_hw: Tuple[int, int] = (384, 384)):
+                 max_hw: Tuple[int, int] = (384, 384), dual: bool = False):
         self.lib = load_library()
         cfg = DptxConfig()
         self.lib.dptx_default_config(C.byref(cfg))
@@ -101,6 +102,7 @@ class Engine:
         cfg.device_id = -1 if device_id is None else int(device_id)
         cfg.non_negative, cfg.ws_form, cfg.ws_eps = int(non_negative), ws_form, ws_eps
         cfg.max_height, cfg.max_width = int(max_hw[0]), int(max_hw[1])
+        cfg.dual_task = int(dual)
         self.cfg = cfg
         self.dtype = dtype
         self.h = _vp()
@@ -169,6 +171,23 @@ class Engine:
             out = torch.empty(B, self.cfg.num_channels, H, W, dtype=torch.float32, device=x.device)
         self._check(self.lib.dptx_forward_hw(self.h, x.data_ptr(), 0, out.data_ptr(), B, H, W, _stream()), "forward")
         return out
+
+    def forward_dual(self, x: torch.Tensor, out_normal: Optional[torch.Tensor] = None,
+                     out_depth: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One encoder pass, two decoders (handle created with dual=True): ([B,3,H,W] normals, [B,1,H,W] depth)."""
+        if not x.is_cuda:
+            raise RuntimeError("dptx forward needs a CUDA(HIP) tensor; there is no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32, got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        if out_normal is None:
+            out_normal = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+        if out_depth is None:
+            out_depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+        self._check(self.lib.dptx_forward_dual(self.h, x.data_ptr(), 0, out_normal.data_ptr(), out_depth.data_ptr(), B, H, W,
+                                               _stream()), "forward_dual")
+        return out_normal, out_depth
 
     def enable_taps(self, on: bool = True):
         self._check(self.lib.dptx_enable_taps(self.h, int(on)), "enable_taps")

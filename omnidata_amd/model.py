@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 
 from .engine import Engine
-from .weights import random_state_dict, read_checkpoint, state_dict_spec
+from .weights import (compose_dual_state_dict, dual_state_dict_spec, random_dual_state_dict, random_state_dict,
+                      read_checkpoint, state_dict_spec)
 
 
 class _Node(nn.Module):
@@ -127,6 +128,91 @@ class DPTDepthModel(BaseModel):
             for i in range(0, B, step):
                 eng.forward(x[i:i + step], out=y[i:i + step])
         return y.squeeze(dim=1)  # dpt_depth.py:106-107
+
+
+class DPTDualTaskModel(nn.Module):
+    """Surface normals AND depth from one encoder pass (BASELINE.json configs[4]).
+
+    ``pretrained.*`` (ResNetV2-50 + ViT-B + read-outs) runs once; ``scratch.*`` (normal decoder, 3 channels) and
+    ``depth.scratch.*`` (depth decoder, 1 channel) both consume its four feature maps: 185.3 GMAC per image
+    instead of 2 x 127.6.  The reference has no such model -- its two checkpoints are independently fine-tuned
+    full networks -- so this is exact only for weights that share ``pretrained.*``; ``from_single_task`` picks
+    which checkpoint donates the encoder.  Both heads see the same input tensor ([0,1] convention).
+
+    forward(x [B,3,H,W]) -> (normal [B,3,H,W], depth [B,H,W]).
+    """
+
+    def __init__(self, dtype: str = "bf16", max_batch: int = 32, init_seed: int = 0, non_negative: bool = True):
+        super().__init__()
+        self.engine_dtype = dtype
+        self.max_batch = max(1, min(int(max_batch), 48))
+        self.max_hw = (384, 384)
+        self.non_negative = bool(non_negative)
+        init = random_dual_state_dict(init_seed)
+        for key in dual_state_dict_spec():
+            *mods, leaf = key.split(".")
+            node = self
+            for m in mods:
+                if not hasattr(node, m):
+                    node.add_module(m, _Node())
+                node = getattr(node, m)
+            node.register_parameter(leaf, nn.Parameter(init[key], requires_grad=False))
+        self._engine: Optional[Engine] = None
+        self._engine_key = None
+        self._weights_version = 0
+
+    @classmethod
+    def from_single_task(cls, normal_sd: Dict[str, torch.Tensor], depth_sd: Dict[str, torch.Tensor],
+                         backbone: str = "normal", **kw) -> "DPTDualTaskModel":
+        m = cls(**kw)
+        m.load_state_dict(compose_dual_state_dict(normal_sd, depth_sd, backbone))
+        return m
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._weights_version += 1
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._weights_version += 1
+        return r
+
+    def _chunk(self) -> int:
+        return max(1, min(self.max_batch, ((1 << 31) - 1) // (self.max_hw[0] * self.max_hw[1] * 256)))
+
+    @property
+    def engine(self) -> Optional[Engine]:
+        return self._engine
+
+    def _get_engine(self, device: torch.device) -> Engine:
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               self._weights_version, self.engine_dtype, self._chunk(), self.max_hw)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            eng = Engine(num_channels=3, max_batch=self._chunk(), dtype=self.engine_dtype, device_id=key[0],
+                         non_negative=self.non_negative, max_hw=self.max_hw, dual=True)
+            eng.load_state_dict(super().state_dict())
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError("omnidata_amd.DPTDualTaskModel runs only on an AMD GPU (HIP); there is no CPU fallback")
+        if x.dim() != 4 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32, got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        if H * W > self.max_hw[0] * self.max_hw[1]:
+            self.max_hw = (H, W)
+        eng = self._get_engine(x.device)
+        step = self._chunk()
+        yn = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+        yd = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+        for i in range(0, B, step):
+            eng.forward_dual(x[i:i + step], out_normal=yn[i:i + step], out_depth=yd[i:i + step])
+        return yn, yd.squeeze(dim=1)
 
 
 def build_model(task: str = "normal", weights: Optional[str] = None, random_weights: Optional[int] = None,

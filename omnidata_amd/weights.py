@@ -113,6 +113,7 @@ def state_dict_spec(num_channels: int = 3, include_unused: bool = True) -> "Orde
 
 UNUSED_KEYS = (
     "pretrained.model.norm.", "pretrained.model.head.", "scratch.refinenet4.resConfUnit1.",
+    "depth.scratch.refinenet4.resConfUnit1.",
 )
 
 
@@ -170,6 +171,48 @@ def random_state_dict(seed: int = 0, num_channels: int = 3, include_unused: bool
             t = s * torch.randn(shape, generator=g, dtype=torch.float32)
         sd[key] = t
     return sd
+
+
+DUAL_PREFIX = "depth."  # second decoder of the dual-task engine: depth.scratch.* (include/dptx.h dptx_forward_dual)
+
+
+def dual_state_dict_spec(include_unused: bool = True) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Keys of the dual-task engine: the normal model's full spec (shared ``pretrained.*`` + ``scratch.*`` with 3
+    channels) followed by the depth decoder's ``scratch.*`` (1 channel) behind the ``depth.`` prefix."""
+    sp = state_dict_spec(3, include_unused)
+    for k, shp in state_dict_spec(1, include_unused).items():
+        if k.startswith("scratch."):
+            sp[DUAL_PREFIX + k] = shp
+    return sp
+
+
+def compose_dual_state_dict(normal_sd: Dict[str, torch.Tensor], depth_sd: Dict[str, torch.Tensor],
+                            backbone: str = "normal") -> Dict[str, torch.Tensor]:
+    """Builds the dual-task state dict from two single-task ones: ``pretrained.*`` from ``backbone`` ('normal' or
+    'depth'), ``scratch.*`` from the normal model, ``depth.scratch.*`` from the depth model."""
+    if backbone not in ("normal", "depth"):
+        raise ValueError("backbone must be 'normal' or 'depth'")
+    src = normal_sd if backbone == "normal" else depth_sd
+    sd: Dict[str, torch.Tensor] = OrderedDict((k, v) for k, v in src.items() if k.startswith("pretrained."))
+    sd.update((k, v) for k, v in normal_sd.items() if k.startswith("scratch."))
+    sd.update((DUAL_PREFIX + k, v) for k, v in depth_sd.items() if k.startswith("scratch."))
+    return sd
+
+
+def split_dual_state_dict(sd: Dict[str, torch.Tensor]):
+    """Inverse view used by the oracle: (normal single-task sd, depth single-task sd) sharing ``pretrained.*``."""
+    shared = OrderedDict((k, v) for k, v in sd.items() if k.startswith("pretrained."))
+    normal = OrderedDict(shared)
+    normal.update((k, v) for k, v in sd.items() if k.startswith("scratch."))
+    depth = OrderedDict(shared)
+    depth.update((k[len(DUAL_PREFIX):], v) for k, v in sd.items() if k.startswith(DUAL_PREFIX))
+    return normal, depth
+
+
+def random_dual_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded dual-task weights: encoder + normal decoder of ``random_state_dict(seed, 3)``, depth decoder of
+    ``random_state_dict(seed + 1000, 1)``."""
+    return compose_dual_state_dict(random_state_dict(seed, 3), random_state_dict(seed + 1000, 1))
 
 
 def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:

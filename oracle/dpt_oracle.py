@@ -262,3 +262,12 @@ def mean_angular_error_deg(pred: Tensor, target: Tensor) -> float:
     b = F.normalize(target.double() * 2 - 1, dim=1, eps=1e-12)
     cos = (a * b).sum(1).clamp(-1, 1)
     return float(torch.rad2deg(torch.acos(cos)).mean())
+
+
+def dpt_forward_dual(sd, x, taps_normal=None, taps_depth=None, **kw):
+    """Dual-task oracle: the reference forward (dpt_depth.py:67-85) run twice on the same
+    input, once per decoder, with `pretrained.*` tied -- which is what a shared-encoder engine must reproduce.
+    `sd` uses the dual key layout of omnidata_amd.weights.dual_state_dict_spec.  Returns (normal, depth)."""
+    from omnidata_amd.weights import split_dual_state_dict
+    normal_sd, depth_sd = split_dual_state_dict(sd)
+    return dpt_forward(normal_sd, x, taps_normal, **kw), dpt_forward(depth_sd, x, taps_depth, **kw)

@@ -20,7 +20,8 @@ def rnd(*shape, dtype="bf16", scale=1.0, seed=0):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1000, 256, 192), (577 * 3, 768, 768), (18464, 2304, 768),
-                                   (4608, 256, 2304), (300, 64, 576), (70000, 64, 64), (5000, 32, 1152), (77, 3072, 768)])
+                                   (4608, 256, 2304), (300, 64, 576), (70000, 64, 64), (5000, 32, 1152), (77, 3072, 768),
+                                   (18464, 768, 3072)])  # last: fc2 at B=32 -> 256x256 8-wave tile
 def test_gemm_plain(dtype, M, N, K):
     # asymmetric, non-identity operands: a row/col swap or a k-permutation mismatch cannot pass
     A, W = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
@@ -32,9 +33,9 @@ def test_gemm_plain(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("M", [1731, 18470])  # 18470 x 768: the 256x256 (8-wave, slab epilogue) tile, ragged last m-tile
-def test_gemm_epilogues(dtype, M):
-    N, K = 768, 768
+@pytest.mark.parametrize("M,K", [(1731, 768), (18470, 2048)])  # 2nd: 256x256 8-wave tile (slab epilogue), ragged last m-tile
+def test_gemm_epilogues(dtype, M, K):
+    N = 768
     A, W = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=4)
     bias = torch.randn(N, device=DEV)
     R16 = rnd(M, N, dtype=dtype, seed=5)
@@ -78,7 +79,7 @@ def conv_ref(X, Wt, bias, stride, pad_t, pad_l, Ho, Wo, a_relu):
     (8, 96, 256, 256, 3, 1, 1, 96, 1, 1, False),   # big-M RCU conv1: 256x256 8-wave tile, pre-ReLU
     (8, 96, 256, 128, 3, 1, 1, 96, 0, 0, True),    # big-M, N=128, residual
     (9, 48, 512, 256, 3, 1, 1, 48, 0, 0, False),   # layer2_rn at batch 9 (M not a multiple of 256)
-    (23, 48, 256, 256, 3, 1, 1, 48, 1, 0, True),   # 256x256 tile, M = 52992 (207 m-tiles), pre-ReLU + residual
+    (25, 48, 256, 256, 3, 1, 1, 48, 1, 0, True),   # 256x256 tile, M = 57600 (225 m-tiles), pre-ReLU + residual
 ])
 def test_conv_implicit_gemm(dtype, case):
     B, H, Cin, Cout, k, stride, pad, Ho, a_relu, act, res = case

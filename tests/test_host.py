@@ -121,3 +121,33 @@ def test_demo_cli_argument_errors(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "demo.py"), "--task", "normal", "--img_path", "x", "--output_path",
                             str(tmp_path), "--random-weights", "0"], capture_output=True, text=True, env=env)
         assert r.returncode != 0 and "needs an AMD GPU" in r.stderr
+
+
+def test_dual_task_spec_and_packing():
+    """Dual-task engine (include/dptx.h dptx_forward_dual): shared encoder keys once + two decoders; host-only pack."""
+    from omnidata_amd.engine import Engine
+    from omnidata_amd.weights import (compose_dual_state_dict, dual_state_dict_spec, random_dual_state_dict, random_state_dict,
+                                      split_dual_state_dict, state_dict_spec)
+    spec = dual_state_dict_spec()
+    n_dec = sum(1 for k in state_dict_spec(1) if k.startswith("scratch."))
+    assert len(spec) == len(state_dict_spec(3)) + n_dec
+    assert spec["depth.scratch.output_conv.4.weight"] == (1, 32, 1, 1) and spec["scratch.output_conv.4.weight"] == (3, 32, 1, 1)
+    sd = random_dual_state_dict(0)
+    assert list(sd.keys()) == list(spec.keys())
+    nsd, dsd = split_dual_state_dict(sd)
+    assert set(nsd) == set(state_dict_spec(3)) and set(dsd) == set(state_dict_spec(1))
+    assert all(nsd[k] is dsd[k] for k in nsd if k.startswith("pretrained."))
+    back = compose_dual_state_dict(nsd, dsd)
+    assert all(back[k] is sd[k] for k in sd)
+    assert compose_dual_state_dict(random_state_dict(0, 3), random_state_dict(1, 1), backbone="depth")[
+        "pretrained.model.cls_token"].equal(random_state_dict(1, 1)["pretrained.model.cls_token"])
+    dual = Engine(num_channels=3, max_batch=1, device_id=None, dual=True)
+    one = Engine(num_channels=3, max_batch=1, device_id=None)
+    dual.load_state_dict(sd)
+    assert dual.packed_bytes > one.packed_bytes
+    blob = dual.export_packed_host()
+    one.load_state_dict(nsd)
+    # the normal model's blob is a prefix of the dual blob (same key order, decoder 2 appended)
+    assert (blob[:one.packed_bytes] == one.export_packed_host()).all()
+    with pytest.raises(RuntimeError):
+        Engine(num_channels=1, max_batch=1, device_id=None, dual=True)  # dual needs the 3-channel primary
