@@ -123,7 +123,9 @@ int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_d
  * 185.29 GMAC per image instead of 2 x 127.62.  This is a composition the reference does not ship (its two checkpoints
  * are separately fine-tuned full models); parity is defined against the reference forward run twice with `pretrained.*`
  * tied.  Needs a handle created with dual_task = 1, num_channels = 3; both heads see the same input tensor.
- *   y_normal_dev [batch,3,height,width], y_depth_dev [batch,1,height,width], NCHW fp32. */
+ *   y_normal_dev [batch,3,height,width], y_depth_dev [batch,1,height,width], NCHW fp32.
+ * dptx_tap after a dual forward: encoder taps as usual, the depth decoder's under "depth.<name>"; the normal decoder's
+ * are not available (its buffers were re-used). */
 int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_normal_dev, void* y_depth_dev,
                       int32_t batch, int32_t height, int32_t width, void* stream);
 

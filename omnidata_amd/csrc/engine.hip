@@ -663,7 +663,12 @@ int Run::forward(const float* x, float* y, float* y2) {
   E->exec_macs += (double)Hi * Wi * 32 * ch;
   };
   decode("", E->cfg.num_channels, y);
-  if (E->cfg.dual_task) decode("depth.", 1, y2);
+  if (E->cfg.dual_task) {
+    // the second decoder re-uses the first one's arena buffers: the first one's stage taps are gone (debug a decoder
+    // with a single-task handle -- its results are bit-identical)
+    for (const char* n : {"l1_rn", "l2_rn", "l3_rn", "l4_rn", "p1", "p2", "p3", "p4", "h0", "h1"}) E->taps.erase(n);
+    decode("depth.", 1, y2);
+  }
   E->last_batch = B;
   if (err != hipSuccess) return E->fail(DPTX_E_HIP, std::string("launch failed at ") + where + ": " + hipGetErrorString(err));
   return DPTX_OK;

@@ -66,8 +66,9 @@ def test_dual_taps_and_contract():
     eng = dual._get_engine(torch.device(DEV))
     eng.enable_taps(True)
     dual(x)
-    assert eng.tap("p1").shape == (2, 256, 192, 192) and eng.tap("depth.p1").shape == (2, 256, 192, 192)
-    assert not torch.equal(eng.tap("l1_rn"), eng.tap("depth.l1_rn"))  # different decoder weights
+    assert eng.tap("s0").shape == (2, 256, 96, 96) and eng.tap("depth.p1").shape == (2, 256, 192, 192)
+    with pytest.raises(RuntimeError, match="unknown or unavailable tap"):
+        eng.tap("p1")  # the depth decoder re-used the normal decoder's buffers
     with pytest.raises(RuntimeError, match="dptx_forward_dual"):
         eng.forward(x)
     one = Engine(num_channels=3, max_batch=1, dtype="bf16", device_id=0)
