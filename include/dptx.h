@@ -210,6 +210,12 @@ int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const fl
 /* bilinear x2, align_corners=True, NHWC 16-bit. */
 int dptx_op_upsample2x(int32_t dtype, const void* X, void* Y, int32_t B, int32_t H, int32_t W,
                        int32_t C, void* stream);
+/* Fused tail of the head (dpt_depth.py:93-98): Interpolate(x2, bilinear, align_corners=True) -> Conv2d(128,32,3,pad 1)
+ * -> ReLU -> Conv2d(32,C,1) -> ReLU(if relu_out).  H0 NHWC 16-bit [B,Hs,Ws,128]; W2 16-bit [32][3][3][128]
+ * (O,kh,kw,I); b2 fp32[32]; w4 fp32 [C][32]; b4 fp32[C]; y NCHW fp32 [B,C,2Hs,2Ws].  BF16 / FP16 only; C <= 3. */
+int dptx_op_head_tail(int32_t dtype, const void* H0, const void* W2, const float* b2, const float* w4,
+                      const float* b4, float* y, int32_t B, int32_t Hs, int32_t Ws, int32_t C,
+                      int32_t relu_out, void* stream);
 
 #ifdef __cplusplus
 }

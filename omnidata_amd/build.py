@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdptx.so")
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "prepost.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip", "prepost.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "dptx.h")]
 
 

@@ -156,6 +156,14 @@ __device__ __forceinline__ void relu8_planes(u32x4_t& hi, u32x4_t& lo) {
   hi = __builtin_bit_cast(u32x4_t, __builtin_elementwise_max(h, zero));
 }
 
+// bilinear blend of a 2x2 neighbourhood in ATen's association, ly0*(lx0*a + lx1*b) + ly1*(lx0*c + lx1*d), with the
+// fused-multiply-adds spelled out so that every kernel that interpolates rounds identically
+__device__ __forceinline__ float bilerp(float a, float b, float c, float d, float lx0, float lx1, float ly0, float ly1) {
+  const float t0 = __fmaf_rn(lx1, b, __fmul_rn(lx0, a));
+  const float t1 = __fmaf_rn(lx1, d, __fmul_rn(lx0, c));
+  return __fmaf_rn(ly1, t1, __fmul_rn(ly0, t0));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));

@@ -227,6 +227,12 @@ struct dptx_engine {
   std::string err;
   std::map<std::string, TapInfo> taps;
   bool taps_on = false;
+  // fused head tail (head.hip): single-plane modes, no stage taps wanted; DPTX_HEAD_FUSED=0 keeps the three launches
+  bool head_fused() const {
+    static int env = -1;
+    if (env < 0) { const char* t = getenv("DPTX_HEAD_FUSED"); env = (t && t[0] == '0') ? 0 : 1; }
+    return env == 1 && cfg.dtype != DPTX_DTYPE_BF16X3 && !taps_on;
+  }
   size_t tok_tap_stride = 0;      // floats per token-stream snapshot
   float* d_tok_taps = nullptr;  // [13][B*577*768] fp32 copies of the token stream (taps_on)
   int64_t launches = 0;
@@ -654,12 +660,22 @@ int Run::forward(const float* x, float* y, float* y2) {
   const std::string oc = pre + "scratch.output_conv.";
   conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, E->a(E->H0), E->f(oc + "0.bias"), 0, 0);
   tap((pre + "h0").c_str(), E->a(E->H0), h2, w2, 128);
-  chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
-  conv(E->a(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, E->a(E->H1), E->f(oc + "2.bias"), 1, 0);
-  tap((pre + "h1").c_str(), E->a(E->H1), Hi, Wi, 32);
-  chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, B, Hi * Wi, ch,
-                      E->cfg.non_negative, E->pl, st),
-      "head.out");
+  if (E->head_fused()) {
+    // x2 upsample + conv 128->32 + ReLU + conv 1x1 + ReLU in one launch (head.hip): the 37.7 MB/image up-sampled map
+    // and the 32-channel map never reach memory.  Not in bf16x3 mode, and not while stage taps are recorded ("h1").
+    chk(launch_head_tail(dt, E->a(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"), E->f(oc + "4.weight"), E->f(oc + "4.bias"),
+                         yout, B, h2, w2, ch, E->cfg.non_negative, st),
+        "head.tail", 0);
+    E->exec_macs += (double)Hi * Wi * 32 * 1152;
+    E->cat_macs[0] += (double)Hi * Wi * 32 * (1152 + ch);
+  } else {
+    chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
+    conv(E->a(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, E->a(E->H1), E->f(oc + "2.bias"), 1, 0);
+    tap((pre + "h1").c_str(), E->a(E->H1), Hi, Wi, 32);
+    chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, B, Hi * Wi, ch,
+                        E->cfg.non_negative, E->pl, st),
+        "head.out");
+  }
   E->exec_macs += (double)Hi * Wi * 32 * ch;
   };
   decode("", E->cfg.num_channels, y);
@@ -959,6 +975,12 @@ int dptx_op_gemm(int32_t dtype, const void* A, const void* W, const float* bias,
   p.A = A; p.W = W; p.C = C; p.bias = bias; p.R1 = R; p.act = act; p.a_fp32 = a_fp32; p.c_fp32 = c_fp32; p.r1_fp32 = r_fp32;
   p.planes = g_op_planes;
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_head_tail(int32_t dtype, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4, float* y,
+                      int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t relu_out, void* stream) {
+  return launch_head_tail(dtype, H0, W2, b2, w4, b4, y, B, Hs, Ws, C, relu_out, (hipStream_t)stream) == hipSuccess ? DPTX_OK
+                                                                                                                : DPTX_E_HIP;
 }
 
 int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias, const void* R, void* Y, int32_t B, int32_t H,

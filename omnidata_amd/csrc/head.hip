@@ -1,0 +1,227 @@
+// head.hip -- the tail of the DPT head in ONE kernel (dpt_depth.py:93-98):
+//   Interpolate(x2, bilinear, align_corners=True) -> Conv2d(128, 32, 3, pad 1) -> ReLU -> Conv2d(32, C, 1) -> ReLU
+//   H0 NHWC 16-bit [B, Hs, Ws, 128]  ->  y NCHW fp32 [B, C, 2Hs, 2Ws]
+//
+// Unfused, this is the most HBM-hungry stretch of the forward: the up-sampled 128-channel map is 37.7 MB per
+// image (written once, read through nine conv taps), the 32-channel map another 9.4 MB -- 1.25 ms of 16.1 ms at
+// B=32.  Here neither exists in memory.  A block owns 8x32 output pixels at a time:
+//   * its 10x34-pixel window of the UP-SAMPLED map is built in LDS (87 KB) straight from the 6x18 source pixels
+//     it depends on: a thread owns one (window column, 8-channel chunk), keeps the 6x2 source vectors it needs in
+//     registers (fetched one tile ahead, so the global latency hides behind the previous tile's MFMAs) and emits
+//     the 10 window rows with the same fp32 formula and the same 16-bit rounding as upsample2x_kernel;
+//   * the whole 3x3 weight tensor [32][9][128] (73.7 KB) lives in LDS for the life of the (persistent) block;
+//   * the conv is 72 v_mfma_f32_32x32x16 per wave (wave w = output row w) with both operands read from LDS
+//     (16-B chunks XOR-swizzled: conflict-free ds_read_b128), computed TRANSPOSED (rows = the 32 output channels,
+//     columns = the 32 pixels) so that a lane ends up with 16 channels of ONE pixel: bias + ReLU + the 1x1
+//     projection to C channels are a 16-term dot product per lane plus one cross-half shuffle, and the result is
+//     stored as 128-B rows of the NCHW fp32 output.
+// k order = (tap, channel), the implicit-GEMM's: the fp32 accumulation sequence is the unfused path's.
+// 576 threads: waves 0-7 own window columns 0..31 and the MFMA rows, wave 8 owns the two halo columns.
+// LDS 161.3 KB -> one block per CU; grid = min(tiles, CUs), each block walks a contiguous run of tiles.
+#include "common.h"
+#include "kernels.h"
+
+namespace dptx {
+
+constexpr int HT_THREADS = 576;
+constexpr int HT_PR = 10, HT_PC = 34;                 // window rows / columns (8x32 outputs + 1-pixel halo)
+constexpr int HT_W_BYTES = 32 * 9 * 256;              // [n][tap][16 chunks x 16 B]
+constexpr int HT_P_BYTES = HT_PR * HT_PC * 256;       // [row][col][16 chunks x 16 B]
+constexpr int HT_CONST_FLOATS = 32 + 3 * 32 + 4;      // bias2, w4 (<= 3 channels), bias4
+constexpr size_t HT_SMEM = HT_W_BYTES + HT_P_BYTES + HT_CONST_FLOATS * 4;
+
+template <int DT>
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+  f[0] = T16<DT>::tof((uint16_t)(v.x & 0xffffu)); f[1] = T16<DT>::tof((uint16_t)(v.x >> 16));
+  f[2] = T16<DT>::tof((uint16_t)(v.y & 0xffffu)); f[3] = T16<DT>::tof((uint16_t)(v.y >> 16));
+  f[4] = T16<DT>::tof((uint16_t)(v.z & 0xffffu)); f[5] = T16<DT>::tof((uint16_t)(v.z >> 16));
+  f[6] = T16<DT>::tof((uint16_t)(v.w & 0xffffu)); f[7] = T16<DT>::tof((uint16_t)(v.w >> 16));
+}
+
+// one window row from source rows J, J+1 of the thread's two source columns
+template <int DT, int J>
+__device__ __forceinline__ u32x4_t lerp_row(const u32x4_t (&S)[6][2], float lx0, float lx1, float ly0, float ly1) {
+  float a[8], b[8], c[8], d[8];
+  unpack8<DT>(S[J][0], a);
+  unpack8<DT>(S[J][1], b);
+  unpack8<DT>(S[J + 1][0], c);
+  unpack8<DT>(S[J + 1][1], d);
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = bilerp(a[e], b[e], c[e], d[e], lx0, lx1, ly0, ly1);
+  u32x4_t r;
+  r.x = T16<DT>::pack2(o[0], o[1]);
+  r.y = T16<DT>::pack2(o[2], o[3]);
+  r.z = T16<DT>::pack2(o[4], o[5]);
+  r.w = T16<DT>::pack2(o[6], o[7]);
+  return r;
+}
+
+template <int DT>
+__global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* __restrict__ H0, const uint16_t* __restrict__ W2,
+                                                               const float* __restrict__ b2, const float* __restrict__ w4,
+                                                               const float* __restrict__ b4, float* __restrict__ y, int B,
+                                                               int Hs, int Ws, int C, int relu_out, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  char* P = smem + HT_W_BYTES;
+  float* cst = (float*)(smem + HT_W_BYTES + HT_P_BYTES);  // [0,32) bias2, [32, 32+32C) w4, [128, 128+C) bias4
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int Ho = 2 * Hs, Wo = 2 * Ws;
+  const int tiles_x = Wo / 32, tiles_y = Ho / 8, tpi = tiles_x * tiles_y;
+  const float ry = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+  const float rx = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+
+  // ---- once per block: weights and constants -> LDS
+  for (int i = tid; i < 32 * 9 * 16; i += HT_THREADS) {
+    const int n = i / 144, rem = i - n * 144, tap = rem >> 4, ch = rem & 15;
+    *(u32x4_t*)(Wl + n * 2304 + tap * 256 + ((ch ^ (n & 15)) << 4)) = *(const u32x4_t*)(W2 + n * 1152 + tap * 128 + ch * 8);
+  }
+  if (tid < 32) cst[tid] = b2[tid];
+  if (tid < 32 * C) cst[32 + tid] = w4[tid];
+  if (tid < C) cst[128 + tid] = b4[tid];
+
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int t_beg = blockIdx.x * per, t_end = min(t_beg + per, ntiles);
+
+  // window column owned by this thread
+  const int wx = tid >> 4, wch = tid & 15;
+  const bool col_thread = wx < HT_PC;
+
+  u32x4_t S[6][2];
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+
+  auto fetch = [&](int t) {  // source vectors of tile t for this thread's column
+    const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int ox = tx * 32 - 1 + wx;
+    const bool vx = col_thread && ox >= 0 && ox < Wo;
+    const float sx = rx * (float)(vx ? ox : 0);
+    const int x0 = (int)sx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const int oyb = max(ty * 8 - 1, 0);
+    const int ybase = (int)(ry * (float)oyb);
+    const uint16_t* img = H0 + (long long)b * Hs * Ws * 128 + wch * 8;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int row = min(ybase + j, Hs - 1);
+      S[j][0] = vx ? *(const u32x4_t*)(img + ((long long)row * Ws + x0) * 128) : zero4;
+      S[j][1] = vx ? *(const u32x4_t*)(img + ((long long)row * Ws + x1) * 128) : zero4;
+    }
+  };
+
+  if (t_beg < t_end) fetch(t_beg);
+  __syncthreads();
+
+  for (int t = t_beg; t < t_end; ++t) {
+    const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 32;
+
+    // ---- up-sampled window -> LDS (zero outside the image: the conv's padding)
+    if (col_thread) {
+      const int ox = ox0 - 1 + wx;
+      const bool vx = ox >= 0 && ox < Wo;
+      const float sx = rx * (float)(vx ? ox : 0);
+      const int x0 = (int)sx;
+      const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+      const int ybase = (int)(ry * (float)max(oy0 - 1, 0));
+      char* dst = P + wx * 256 + ((wch ^ (wx & 15)) << 4);
+      for (int r = 0; r < HT_PR; ++r) {
+        const int oy = oy0 - 1 + r;
+        u32x4_t o = zero4;
+        if (vx && oy >= 0 && oy < Ho) {
+          const float sy = ry * (float)oy;
+          const int y0 = (int)sy;
+          const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+          switch (y0 - ybase) {  // uniform over the block; slot j+1 holds row min(y0+1, Hs-1) = ATen's y1
+            case 0: o = lerp_row<DT, 0>(S, lx0, lx1, ly0, ly1); break;
+            case 1: o = lerp_row<DT, 1>(S, lx0, lx1, ly0, ly1); break;
+            case 2: o = lerp_row<DT, 2>(S, lx0, lx1, ly0, ly1); break;
+            case 3: o = lerp_row<DT, 3>(S, lx0, lx1, ly0, ly1); break;
+            default: o = lerp_row<DT, 4>(S, lx0, lx1, ly0, ly1); break;
+          }
+        }
+        *(u32x4_t*)(dst + r * (HT_PC * 256)) = o;
+      }
+    }
+    if (t + 1 < t_end) fetch(t + 1);  // in flight across the barrier and the MFMA phase
+    __syncthreads();
+
+    // ---- 3x3 conv 128 -> 32 on the window, transposed: acc[r] = channel (r&3)+8(r>>2)+4*lh of pixel lr
+    if (wave < 8) {
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const char* wrow = Wl + lr * 2304;
+      const int wkey = lr & 15;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int xc = lr + kx;
+        const char* prow = P + ((wave + ky) * HT_PC + xc) * 256;
+        const int pkey = xc & 15;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+          const int chunk = 2 * cb + lh;
+          const u32x4_t wf = *(const u32x4_t*)(wrow + tap * 256 + ((chunk ^ wkey) << 4));
+          const u32x4_t pf = *(const u32x4_t*)(prow + ((chunk ^ pkey) << 4));
+          acc = T16<DT>::mfma32(wf, pf, acc);
+        }
+      }
+      // ---- bias + ReLU, 1x1 conv to C channels, final ReLU, NCHW fp32 rows
+      float h[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bb = *(const float4*)(cst + 8 * q + 4 * lh);
+        h[4 * q + 0] = fmaxf(acc[4 * q + 0] + bb.x, 0.f);
+        h[4 * q + 1] = fmaxf(acc[4 * q + 1] + bb.y, 0.f);
+        h[4 * q + 2] = fmaxf(acc[4 * q + 2] + bb.z, 0.f);
+        h[4 * q + 3] = fmaxf(acc[4 * q + 3] + bb.w, 0.f);
+      }
+      const int oy = oy0 + wave;
+      for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 ww = *(const float4*)(cst + 32 + c * 32 + 8 * q + 4 * lh);
+          s += ww.x * h[4 * q + 0] + ww.y * h[4 * q + 1] + ww.z * h[4 * q + 2] + ww.w * h[4 * q + 3];
+        }
+        s += __shfl_xor(s, 32);
+        s += cst[128 + c];
+        if (relu_out) s = fmaxf(s, 0.f);
+        if ((c & 1) == lh) y[(((long long)b * C + c) * Ho + oy) * Wo + ox0 + lr] = s;
+      }
+    }
+    __syncthreads();  // the window is rebuilt for the next tile
+  }
+}
+
+hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
+                            float* y, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream) {
+  if (mode == MODE_BF16X3 || C < 1 || C > 3 || (2 * Hs) % 8 != 0 || (2 * Ws) % 32 != 0) return hipErrorInvalidValue;
+  const int ntiles = B * ((2 * Hs) / 8) * ((2 * Ws) / 32);
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int grid = ntiles < cus ? ntiles : cus;
+  if (mode == MODE_BF16) {
+    auto k = head_tail_kernel<DT_BF16>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_SMEM); done = true; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(HT_THREADS), HT_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, B,
+                       Hs, Ws, C, relu_out, ntiles);
+  } else {
+    auto k = head_tail_kernel<DT_FP16>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_SMEM); done = true; }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(HT_THREADS), HT_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, B,
+                       Hs, Ws, C, relu_out, ntiles);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace dptx

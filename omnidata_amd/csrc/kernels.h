@@ -77,6 +77,9 @@ hipError_t launch_head_out(int mode, const void* X, const float* w, const float*
                            int Cout, int relu, Planes pl, hipStream_t stream);
 
 // X[b*577] = cls + pos[0]  (fp32 token stream)
+// fused tail of the head: x2 bilinear -> conv3x3 128->32 -> ReLU -> conv1x1 32->C -> ReLU (head.hip; not in bf16x3 mode)
+hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
+                            float* y, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream);
 hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, int gw, int C, hipStream_t stream);
 hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, int S, int C, hipStream_t stream);
 

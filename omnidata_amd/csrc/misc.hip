@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restr
   load8f<DT, PL>(img + (y1 * W + x0) * C, plane, c);
   load8f<DT, PL>(img + (y1 * W + x1) * C, plane, d);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);
+  for (int e = 0; e < 8; ++e) o[e] = bilerp(a[e], bb[e], c[e], d[e], lx0, lx1, ly0, ly1);
   store8f<DT, PL>(Y + ((long long)blockIdx.y * Wo + ox) * C + v * 8, plane, o);
 }
 

@@ -19,7 +19,7 @@ def disasm(src, tmp_path):
     return out.read_text()
 
 
-@pytest.mark.parametrize("src", ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip"])
+@pytest.mark.parametrize("src", ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip"])
 def test_no_scratch_no_spills(src, tmp_path):
     s = disasm(src, tmp_path)
     names = re.findall(r"^\s+\.name:\s+(\S+)", s, flags=re.M)

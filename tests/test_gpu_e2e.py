@@ -144,3 +144,26 @@ def test_input_contract_errors():
     assert y.shape == (1, 384, 384)
     n, alg, exe = model.engine.info()
     assert n > 200 and abs(alg - 127.615e9) < 1e6 and 120e9 < exe < 130e9
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_fused_head_equals_unfused(dtype):
+    """The one-launch head tail (head.hip) against the three-launch path the engine takes while stage taps are on: the
+    only differences are the un-rounded 32-channel map (kept in fp32 registers instead of 16-bit memory) and the fp32
+    summation order of the 1x1 projection."""
+    sd = random_state_dict(2, 3)
+    model = DPTDepthModel(num_channels=3, dtype=dtype, max_batch=2)
+    model.load_state_dict(sd)
+    model.to(DEV)
+    x = synthetic_input(3, 2, "normal").to(DEV)
+    y_fused = model(x).clone()
+    eng = model.engine
+    launches_fused = eng.info()[0]
+    eng.enable_taps(True)
+    y_unfused = model(x).clone()
+    assert eng.info()[0] == launches_fused + 2
+    eng.enable_taps(False)
+    d = (y_fused - y_unfused).abs().max().item()
+    print(f"\n[{dtype}] fused vs unfused head tail: max|d| = {d:.3e}")
+    assert d < (4e-3 if dtype == "bf16" else 5e-4)  # half a 16-bit ulp of h1 (|h1| ~ 1) times sum|w4| ~ 1
+    assert torch.equal(model(x), y_fused)

@@ -172,3 +172,35 @@ def test_fused_stem_conv(dtype, B, H, W):
     ref = F.conv2d(F.pad(x.to(TDT[dtype]).float(), [2, 3, 2, 3]), w.to(TDT[dtype]).float(), None, 2).permute(0, 2, 3, 1)
     assert ref.shape == y.shape
     assert rel_err(y.float(), ref) < OUT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,Hs,Ws,C,relu", [(2, 48, 64, 3, 1), (1, 192, 192, 1, 1), (3, 32, 48, 3, 0), (5, 16, 16, 2, 1)])
+def test_fused_head_tail(dtype, B, Hs, Ws, C, relu):
+    """x2 bilinear (align_corners) -> conv3x3 128->32 -> ReLU -> conv1x1 32->C -> ReLU in one kernel (head.hip), against
+    the same chain in fp32 torch on the same 16-bit inputs (the up-sampled map rounded to 16 bit, as the kernel does)."""
+    lib = load_library()
+    H0 = rnd(B, Hs, Ws, 128, dtype=dtype, seed=21)
+    W2 = rnd(32, 3, 3, 128, dtype=dtype, scale=1152 ** -0.5, seed=22)
+    b2 = torch.randn(32, device=DEV) * 0.3
+    w4 = torch.randn(C, 32, device=DEV) * 0.3
+    b4 = torch.randn(C, device=DEV) * 0.2
+    y = torch.full((B, C, 2 * Hs, 2 * Ws), float("nan"), device=DEV)
+    assert lib.dptx_op_head_tail(DTYPES[dtype], ptr(H0), ptr(W2), ptr(b2), ptr(w4), ptr(b4), ptr(y), B, Hs, Ws, C, relu, stream()) == 0
+    up = F.interpolate(H0.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+    up = up.to(TDT[dtype]).float()
+    h = F.relu(F.conv2d(up, W2.float().permute(0, 3, 1, 2), b2, padding=1))
+    ref = F.conv2d(h, w4.view(C, 32, 1, 1), b4)
+    if relu:
+        ref = F.relu(ref)
+    assert torch.isfinite(y).all()
+    # a 16-bit rounding of the up-sampled map can flip where the two fp32 interpolation formulas differ in the last bit
+    assert rel_err(y, ref) < 2e-3 * (1 if dtype == "bf16" else 0.2)
+    # and against this library's own unfused kernels the result is the same up to fp32 summation order
+    U = torch.empty(B, 2 * Hs, 2 * Ws, 128, device=DEV, dtype=TDT[dtype])
+    assert lib.dptx_op_upsample2x(DTYPES[dtype], ptr(H0), ptr(U), B, Hs, Ws, 128, stream()) == 0
+    h2 = F.relu(F.conv2d(U.float().permute(0, 3, 1, 2), W2.float().permute(0, 3, 1, 2), b2, padding=1))
+    ref2 = F.conv2d(h2, w4.view(C, 32, 1, 1), b4)
+    if relu:
+        ref2 = F.relu(ref2)
+    assert rel_err(y, ref2) < 2e-5
