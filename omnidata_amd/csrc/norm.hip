@@ -132,16 +132,33 @@ hipError_t launch_gn_stats(int mode, const void* X, float* partial, int B, int H
   return hipGetLastError();
 }
 
-// per-channel affine (a, d) with y = x*a + d from chunk partials; called by every thread of a block
+// per-channel affine (a, d) with y = x*a + d from chunk partials; called by every thread of a 256-thread block.
+// The chunk partials are summed in double by 8 slices of 32 threads (slice s takes chunks s, s+8, ...: the loads of
+// one slice are independent, so the latency is nchunks/8 dependent adds instead of nchunks dependent loads) and the
+// slices are combined in a fixed order: the result depends on HW and C only, never on the batch or the run.
 __device__ __forceinline__ void gn_affine_to_lds(const float* __restrict__ partial, int nchunks, int b,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int C,
                                                  int HW, float eps, float* sa, float* sd, float* smr) {
+  __shared__ double sred[8][GN_G][2];
   const int tid = threadIdx.x;
   const int cpg = C >> 5;
+  {
+    const int g = tid & (GN_G - 1), slice = tid >> 5;
+    double ss = 0.0, qq = 0.0;
+    const float2* pp = (const float2*)partial + (long long)b * nchunks * GN_G + g;
+    for (int c = slice; c < nchunks; c += 8) {
+      const float2 v = pp[(long long)c * GN_G];
+      ss += (double)v.x;
+      qq += (double)v.y;
+    }
+    sred[slice][g][0] = ss;
+    sred[slice][g][1] = qq;
+  }
+  __syncthreads();
   if (tid < GN_G) {
     double ss = 0.0, qq = 0.0;
-    const float* pp = partial + ((long long)b * nchunks * GN_G + tid) * 2;
-    for (int c = 0; c < nchunks; ++c) { ss += (double)pp[(long long)c * GN_G * 2]; qq += (double)pp[(long long)c * GN_G * 2 + 1]; }
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) { ss += sred[sl][tid][0]; qq += sred[sl][tid][1]; }
     const double n = (double)HW * (double)cpg;
     const double mean = ss / n;
     double var = qq / n - mean * mean;
@@ -250,7 +267,8 @@ hipError_t launch_gn_relu_maxpool(int mode, const void* X, void* Y, const float*
                                   const float* partial, int B, int H, int W, int C, float eps, Planes pl, hipStream_t stream) {
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int total = Ho * Wo * (C / 8);
-  dim3 grid(min((total + 255) / 256, 1024), B);
+  // few, fat blocks: every block re-reduces the chunk partials of its image in its prologue
+  dim3 grid(min((total + 255) / 256, 64), B);
   const int nch = gn_chunks(H * W);
   DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_relu_maxpool_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X,
                                               (uint16_t*)Y, gamma, beta, partial, nch, H, W, C, eps, pl.act));
