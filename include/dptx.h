@@ -203,7 +203,8 @@ int dptx_op_attention(int32_t dtype, const void* qkv, void* out, int32_t B, int3
 /* y16[M,768] = LayerNorm(x32[M,768]; gamma, beta, eps) */
 int dptx_op_layernorm(int32_t dtype, const float* x, const float* gamma, const float* beta,
                       void* y, int32_t M, int32_t C, float eps, void* stream);
-/* GroupNorm(32) (+ optional residual R, + optional ReLU) on NHWC 16-bit, out of place. */
+/* GroupNorm(32) (+ optional residual R, + optional ReLU) on NHWC 16-bit, out of place.  scratch_f32 receives the
+ * per-block partial sums: B * ceil(HW / pix) * 64 floats with pix = clamp(16384 / C, 16, 256). */
 int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const float* beta,
                       const void* R, void* Y, int32_t B, int32_t HW, int32_t C, int32_t relu,
                       float eps, void* scratch_f32, void* stream);

@@ -59,7 +59,7 @@ struct GnParams {
   int B, HW, C, relu;
   float eps;
 };
-int gn_chunks(int HW);
+int gn_chunks(int HW, int C);  // blocks per image of the GroupNorm stats/apply grids = partial records per image
 hipError_t launch_gn_stats(int mode, const void* X, float* partial, int B, int HW, int C, Planes pl, hipStream_t stream);
 hipError_t launch_gn_apply(int mode, const GnParams& p, Planes pl, hipStream_t stream);
 // stem: Y[B,Ho,Wo,C] = maxpool3x3s2_SAME( relu(gn(X[B,H,W,C])) )

@@ -68,11 +68,16 @@ hipError_t launch_layernorm(int mode, const float* x, const float* gamma, const 
 // partials in double (fixed order) in its prologue, so no atomics and no finalize launch.
 constexpr int GN_G = 32;
 
-int gn_chunks(int HW) {
-  const int pix = HW <= 2304 ? 64 : 256;
+// pixels per block: ~32 KB of the tensor (256 px at C = 64 ... 16 px at C = 1024) -- a function of the layer only, never
+// of the batch, so that the partial-sum order (and with it every output bit) is the same at any batch size
+static inline int gn_pix(int C) {
+  const int pix = 16384 / C;
+  return pix < 16 ? 16 : (pix > 256 ? 256 : pix);
+}
+int gn_chunks(int HW, int C) {
+  const int pix = gn_pix(C);
   return (HW + pix - 1) / pix;
 }
-static inline int gn_pix(int HW) { return HW <= 2304 ? 64 : 256; }
 
 template <int DT, int PL>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X, float* __restrict__ partial,
@@ -126,9 +131,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
 
 hipError_t launch_gn_stats(int mode, const void* X, float* partial, int B, int HW, int C, Planes pl, hipStream_t stream) {
   if (C % 64 != 0 || C > 1024 || (256 % (C / 8)) != 0) return hipErrorInvalidValue;
-  dim3 grid(gn_chunks(HW), B);
+  dim3 grid(gn_chunks(HW, C), B);
   DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_stats_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X, partial,
-                                              HW, C, gn_pix(HW), pl.act));
+                                              HW, C, gn_pix(C), pl.act));
   return hipGetLastError();
 }
 
@@ -218,9 +223,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix
 
 hipError_t launch_gn_apply(int mode, const GnParams& p, Planes pl, hipStream_t stream) {
   if (p.C % 64 != 0 || p.C > 1024) return hipErrorInvalidValue;
-  const int nch = gn_chunks(p.HW);
+  const int nch = gn_chunks(p.HW, p.C);
   dim3 grid(nch, p.B);
-  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_apply_kernel<DT, PL>), grid, dim3(256), 0, stream, p, gn_pix(p.HW), nch, pl.act));
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_apply_kernel<DT, PL>), grid, dim3(256), 0, stream, p, gn_pix(p.C), nch, pl.act));
   return hipGetLastError();
 }
 
@@ -269,7 +274,7 @@ hipError_t launch_gn_relu_maxpool(int mode, const void* X, void* Y, const float*
   const int total = Ho * Wo * (C / 8);
   // few, fat blocks: every block re-reduces the chunk partials of its image in its prologue
   dim3 grid(min((total + 255) / 256, 64), B);
-  const int nch = gn_chunks(H * W);
+  const int nch = gn_chunks(H * W, C);
   DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_relu_maxpool_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X,
                                               (uint16_t*)Y, gamma, beta, partial, nch, H, W, C, eps, pl.act));
   return hipGetLastError();

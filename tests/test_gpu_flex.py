@@ -65,14 +65,17 @@ def test_flex_vs_reference_golden(path):
                                               ("normal", 3, 8, 3, (64, 96))])
 def test_flex_vs_oracle(task, C, seed, B, hw):
     sd, x, ref, otaps = oracle_case(task, C, seed, B, hw)
-    for dtype, tol in (("bf16", E2E_TOL["bf16"][0]), ("bf16x3", 1e-3)):
+    # bf16: the max over ~1e5..1e6 outputs of a heavy-tailed rounding error moves between 4e-2 and 8.5e-2 with seed and
+    # size (E2E_TOL's 8e-2 was set on the three 384x384 cases); the rms is the stable figure and keeps E2E_TOL's budget
+    for dtype, tol in (("bf16", 1.2e-1), ("bf16x3", 1e-3)):
         model = make_model(sd, C, dtype, B)
         eng = model._get_engine(torch.device(DEV)) if hw[0] * hw[1] <= 384 * 384 else None
         y = model(x.to(DEV)).cpu()
         assert y.shape == ref.shape and torch.isfinite(y).all()
         d = (y - ref).abs().max().item()
-        print(f"\n[{task} {hw[0]}x{hw[1]} B={B} {dtype}] max|d|={d:.3e}")
-        assert d < tol
+        rms = (y - ref).pow(2).mean().sqrt().item()
+        print(f"\n[{task} {hw[0]}x{hw[1]} B={B} {dtype}] max|d|={d:.3e} rms={rms:.3e}")
+        assert d < tol and rms < E2E_TOL["bf16"][1]
         if eng is not None and dtype == "bf16":  # stage taps have the right geometry too
             eng.enable_taps(True)
             model(x.to(DEV))
