@@ -196,8 +196,8 @@ size_t packed_entry_bytes(const Spec& s) {
   }
 }
 
-struct Buf {  // arena slice
-  size_t off = 0, bytes = 0;
+struct Buf {  // arena slice: `off` in the whole-batch plan, `off2` in the half-batch plan (two sub-batches on two streams)
+  size_t off = 0, bytes = 0, off2 = 0;
 };
 
 struct TapInfo {
@@ -247,6 +247,12 @@ struct dptx_engine {
   int64_t cat_launches[4] = {0, 0, 0, 0};
   double cat_macs[4] = {0, 0, 0, 0};
 
+  // two sub-batches on two internal streams (MFMA-bound and HBM-bound launches of the two halves overlap, tails fill)
+  int n_streams = 2;              // cfg.streams (0 = default 2); 1 = everything on the caller's stream
+  int half_batch = 0;             // images per half-batch region
+  size_t half_region = 0;         // bytes of one half-batch region (two of them fit in one arena plane)
+  hipStream_t sub_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   // arena slices
   int max_h = 384, max_w = 384;   // largest supported input (cfg.max_height/max_width; 0 = 384)
   int pos_gh = 0, pos_gw = 0;     // grid of the resized pos_embed currently held in pos_alt
@@ -271,16 +277,17 @@ namespace {
     if (_r != hipSuccess) return (e)->fail(DPTX_E_HIP, std::string(#call) + ": " + hipGetErrorString(_r)); \
   } while (0)
 
-void plan_arena(dptx_engine* e) {
-  const size_t B = (size_t)e->cfg.max_batch;
+// Bump-allocates every activation buffer for Bn images; half = false fills Buf::off (one run over the whole batch),
+// half = true fills Buf::off2 (layout of ONE of the two half-batch regions).  Returns the bytes used.
+size_t plan_arena_for(dptx_engine* e, size_t B, bool half) {
   // every buffer scales with the pixel count of the largest supported input (H, W multiples of 32); P = H*W
   const size_t P = (size_t)e->max_h * e->max_w;
   const size_t p2 = P / 4, p4 = P / 16, p8 = P / 64, p16 = P / 256, p32 = P / 1024, S = p16 + 1;
   size_t off = 0;
   auto take = [&](Buf& b, size_t elems, size_t esz) {
-    b.off = off;
-    b.bytes = align_up(elems * esz, 256);
-    off += b.bytes;
+    const size_t bytes = align_up(elems * esz, 256);
+    if (half) b.off2 = off; else { b.off = off; b.bytes = bytes; }
+    off += bytes;
   };
   take(e->sraw, B * p2 * 64, 2);
   take(e->stem, B * p4 * 64, 2);
@@ -315,6 +322,14 @@ void plan_arena(dptx_engine* e) {
   take(e->H0, B * p2 * 128, 2);
   take(e->H0U, B * P * 128, 2);
   take(e->H1, B * P * 32, 2);
+  return off;
+}
+
+void plan_arena(dptx_engine* e) {
+  const size_t full = plan_arena_for(e, (size_t)e->cfg.max_batch, false);
+  e->half_batch = (e->cfg.max_batch + 1) / 2;
+  e->half_region = align_up(plan_arena_for(e, (size_t)e->half_batch, true), 256);
+  const size_t off = std::max(full, 2 * e->half_region);
   e->arena_single = off;
   const int npl = e->cfg.dtype == DPTX_DTYPE_BF16X3 ? 2 : 1;
   e->arena_bytes = off * npl;
@@ -391,12 +406,18 @@ struct Run {
   hipStream_t st;
   int dt;
   int Hi = 384, Wi = 384;  // input size (multiples of 32)
+  size_t abase = 0;        // byte offset of this run's arena region
+  bool half = false;       // half-batch plan (Buf::off2) instead of the whole-batch plan
   hipError_t err = hipSuccess;
   const char* where = "";
+  int64_t launches = 0;    // accounting of this run (copied to the engine by the caller)
+  double exec_macs = 0.0, cat_macs[4] = {0, 0, 0, 0};
+
+  char* A(const Buf& b) const { return e->d_arena + abase + (half ? b.off2 : b.off); }
 
   void chk(hipError_t r, const char* w, int cat = 3) {
     if (err == hipSuccess && r != hipSuccess) { err = r; where = w; }
-    e->launches++;
+    launches++;
     if (e->profiling) {
       const size_t i = e->event_cat.size() + 1;  // events[0] marks the start of the forward
       if (i >= e->events.size()) {
@@ -426,8 +447,8 @@ struct Run {
     p.ksz = ksz; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
     p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = Cout;
     p.act = act; p.a_relu = a_relu; p.planes = e->pl;
-    e->exec_macs += (double)p.M / B * p.N * p.K;
-    e->cat_macs[0] += (double)p.M / B * p.N * p.K;
+    exec_macs += (double)p.M / B * p.N * p.K;
+    cat_macs[0] += (double)p.M / B * p.N * p.K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
   }
 
@@ -454,9 +475,6 @@ struct Run {
 int Run::forward(const float* x, float* y, float* y2) {
   dptx_engine* E = e;
   E->taps.clear();
-  E->launches = 0;
-  E->exec_macs = 0.0;
-  for (int c = 0; c < 4; ++c) E->cat_macs[c] = 0.0;
   E->event_cat.clear();
   E->event_name.clear();
   if (E->profiling) {
@@ -468,32 +486,32 @@ int Run::forward(const float* x, float* y, float* y2) {
   }
   const std::string vp = "pretrained.model.";
   const std::string bp = vp + "patch_embed.backbone.";
-  float* part0 = (float*)E->a(E->part[0]);
-  float* part1 = (float*)E->a(E->part[1]);
-  float* part2 = (float*)E->a(E->part[2]);
-  float* part3 = (float*)E->a(E->part[3]);
+  float* part0 = (float*)A(E->part[0]);
+  float* part1 = (float*)A(E->part[1]);
+  float* part2 = (float*)A(E->part[2]);
+  float* part3 = (float*)A(E->part[3]);
   const int h2 = Hi / 2, w2 = Wi / 2, h4 = Hi / 4, w4 = Wi / 4, gh = Hi / 16, gw = Wi / 16, h32 = Hi / 32, w32 = Wi / 32;
   const int NP = gh * gw;   // patch tokens per image (576 at 384x384)
   const int S = NP + 1;     // + cls
   const bool native = (gh == 24 && gw == 24);
   const float* pos = E->f("pretrained.model.pos_embed");
   if (!native) {  // vit.py:119-125: forward_flex resizes pos_embed to the input's patch grid on every call
-    chk(launch_pos_resize(pos, (float*)E->a(E->pos_alt), 24, gh, gw, D_VIT, st), "pos_resize");
-    pos = (const float*)E->a(E->pos_alt);
+    chk(launch_pos_resize(pos, (float*)A(E->pos_alt), 24, gh, gw, D_VIT, st), "pos_resize");
+    pos = (const float*)A(E->pos_alt);
   }
 
   // ---- stem: fused conv7x7 s2 SAME (stem.hip, no im2col) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
-  chk(launch_stem_conv(dt, x, E->w(bp + "stem.conv.weight"), E->a(E->sraw), B, Hi, Wi, E->pl, st), "stem.conv", 0);
-  E->exec_macs += (double)h2 * w2 * 64 * STEM_K;
-  E->cat_macs[0] += (double)h2 * w2 * 64 * STEM_K;
-  gn_stats(E->a(E->sraw), part0, h2 * w2, 64);
-  chk(launch_gn_relu_maxpool(dt, E->a(E->sraw), E->a(E->stem), E->f(bp + "stem.norm.weight"), E->f(bp + "stem.norm.bias"),
+  chk(launch_stem_conv(dt, x, E->w(bp + "stem.conv.weight"), A(E->sraw), B, Hi, Wi, E->pl, st), "stem.conv", 0);
+  exec_macs += (double)h2 * w2 * 64 * STEM_K;
+  cat_macs[0] += (double)h2 * w2 * 64 * STEM_K;
+  gn_stats(A(E->sraw), part0, h2 * w2, 64);
+  chk(launch_gn_relu_maxpool(dt, A(E->sraw), A(E->stem), E->f(bp + "stem.norm.weight"), E->f(bp + "stem.norm.bias"),
                              part0, B, h2, w2, 64, 1e-5f, E->pl, st),
       "stem.pool", 2);
-  tap("stem", E->a(E->stem), h4, w4, 64);
+  tap("stem", A(E->stem), h4, w4, 64);
 
   // ---- ResNetV2 stages (3,4,9) non-preact bottlenecks -----------------------------------
-  const void* cur = E->a(E->stem);
+  const void* cur = A(E->stem);
   int H = h4, Wd = w4, cin = 64;
   for (int s = 0; s < 3; ++s) {
     const int cout = STAGE_OUT[s], mid = cout / 4;
@@ -501,23 +519,23 @@ int Run::forward(const float* x, float* y, float* y2) {
       const std::string p = bp + "stages." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
       const int stride = (b == 0) ? STAGE_STRIDE[s] : 1;
       const int Ho = H / stride, Wo = Wd / stride;
-      void* out = (b == STAGE_DEPTH[s] - 1) ? (void*)E->a(E->S[s]) : (void*)((b & 1) ? E->a(E->PB) : E->a(E->PA));
+      void* out = (b == STAGE_DEPTH[s] - 1) ? (void*)A(E->S[s]) : (void*)((b & 1) ? A(E->PB) : A(E->PA));
       if (b == 0) {
-        conv(cur, H, Wd, cin, p + "downsample.conv.weight", 1, stride, 0, 0, Ho, Wo, cout, E->a(E->DS), nullptr, 0, 0);
-        gn_stats(E->a(E->DS), part3, Ho * Wo, cout);
+        conv(cur, H, Wd, cin, p + "downsample.conv.weight", 1, stride, 0, 0, Ho, Wo, cout, A(E->DS), nullptr, 0, 0);
+        gn_stats(A(E->DS), part3, Ho * Wo, cout);
       }
-      conv(cur, H, Wd, cin, p + "conv1.weight", 1, 1, 0, 0, H, Wd, mid, E->a(E->T1), nullptr, 0, 0);
-      gn_stats(E->a(E->T1), part0, H * Wd, mid);
-      gn_apply(E->a(E->T1), p + "norm1", part0, H * Wd, mid, 1);
+      conv(cur, H, Wd, cin, p + "conv1.weight", 1, 1, 0, 0, H, Wd, mid, A(E->T1), nullptr, 0, 0);
+      gn_stats(A(E->T1), part0, H * Wd, mid);
+      gn_apply(A(E->T1), p + "norm1", part0, H * Wd, mid, 1);
       // 3x3, stride on conv2 (V1.5); TF-SAME: s1 -> pad (1,1); s2 on even H -> pad (0,1)
       const int pad = (stride == 1) ? 1 : 0;
-      conv(E->a(E->T1), H, Wd, mid, p + "conv2.weight", 3, stride, pad, pad, Ho, Wo, mid, E->a(E->T2), nullptr, 0, 0);
-      gn_stats(E->a(E->T2), part1, Ho * Wo, mid);
-      gn_apply(E->a(E->T2), p + "norm2", part1, Ho * Wo, mid, 1);
-      conv(E->a(E->T2), Ho, Wo, mid, p + "conv3.weight", 1, 1, 0, 0, Ho, Wo, cout, out, nullptr, 0, 0);
+      conv(A(E->T1), H, Wd, mid, p + "conv2.weight", 3, stride, pad, pad, Ho, Wo, mid, A(E->T2), nullptr, 0, 0);
+      gn_stats(A(E->T2), part1, Ho * Wo, mid);
+      gn_apply(A(E->T2), p + "norm2", part1, Ho * Wo, mid, 1);
+      conv(A(E->T2), Ho, Wo, mid, p + "conv3.weight", 1, 1, 0, 0, Ho, Wo, cout, out, nullptr, 0, 0);
       gn_stats(out, part2, Ho * Wo, cout);
       if (b == 0)
-        gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, E->a(E->DS), p + "downsample.norm", part3);
+        gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, A(E->DS), p + "downsample.norm", part3);
       else
         gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, cur);
       cur = out;
@@ -530,16 +548,16 @@ int Run::forward(const float* x, float* y, float* y2) {
   }
 
   // ---- tokens: 1x1 proj + bias + pos_embed -> fp32 stream X[b*577 + 1 + p]; cls rows ----
-  float* X = (float*)E->a(E->X);
+  float* X = (float*)A(E->X);
   {
     GemmParams p;
     gemm_params_dense(p, B * NP, D_VIT, 1024);
-    p.A = E->a(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
+    p.A = A(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
     p.bias = E->f(vp + "patch_embed.proj.bias");
     p.c_rpi = NP; p.c_img_rows = S; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
     p.R2 = pos; p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
-    E->exec_macs += (double)NP * D_VIT * 1024;
-    E->cat_macs[0] += (double)NP * D_VIT * 1024;
+    exec_macs += (double)NP * D_VIT * 1024;
+    cat_macs[0] += (double)NP * D_VIT * 1024;
     chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
   }
   chk(launch_cls_rows(E->f(vp + "cls_token"), pos, X, B, S, D_VIT, st), "cls_rows");
@@ -559,24 +577,24 @@ int Run::forward(const float* x, float* y, float* y2) {
     gemm_params_dense(p, M, N, K);
     p.A = A; p.a_fp32 = a_fp32; p.W = E->w(wkey); p.C = C; p.c_fp32 = c_fp32; p.bias = bias; p.act = act;
     p.R1 = R1; p.r1_fp32 = r1_fp32; p.planes = E->pl;
-    E->exec_macs += (double)S * N * K;
-    E->cat_macs[0] += (double)S * N * K;
+    exec_macs += (double)S * N * K;
+    cat_macs[0] += (double)S * N * K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
   };
 
   // ProjectReadout + reassemble for hook n (3 -> block 8, 4 -> block 11)
   auto readout = [&](int n) {
     const std::string pp = "pretrained.act_postprocess" + std::to_string(n) + ".";
-    float* clsb = (float*)E->a(E->clsb);
+    float* clsb = (float*)A(E->clsb);
     chk(launch_readout_cls(dt, X, (long long)S * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT, D_VIT,
                            E->f(pp + "0.project.0.bias"), clsb, B, D_VIT, D_VIT, E->pl, st),
         "readout_cls");
     // the token GEMM reads a 16-bit image of the fp32 stream (Hn is free between blocks)
-    chk(launch_cast_f32(dt, X, E->a(E->Hn), (size_t)B * S * D_VIT, E->pl, st), "readout_cast");
-    E->exec_macs += (double)D_VIT * D_VIT;  // per image
-    void* R = (n == 3) ? E->a(E->R3) : E->a(E->R4);
+    chk(launch_cast_f32(dt, X, A(E->Hn), (size_t)B * S * D_VIT, E->pl, st), "readout_cast");
+    exec_macs += (double)D_VIT * D_VIT;  // per image
+    void* R = (n == 3) ? A(E->R3) : A(E->R4);
     GemmParams p{};
-    p.A = E->a(E->Hn); p.a_bytes = (long long)B * S * D_VIT * 2; p.planes = E->pl;
+    p.A = A(E->Hn); p.a_bytes = (long long)B * S * D_VIT * 2; p.planes = E->pl;
     p.W = E->w(pp + "0.project.0.weight"); p.ldw = 2 * D_VIT; p.C = R;
     p.M = B * NP; p.N = D_VIT; p.K = D_VIT;
     p.a_rpi = NP; p.Wout = NP; p.Hin = 1; p.Win = NP; p.Cin = D_VIT; p.a_pix_stride = D_VIT;
@@ -584,31 +602,31 @@ int Run::forward(const float* x, float* y, float* y2) {
     p.ksz = 1; p.stride = 1;
     p.c_rpi = NP; p.c_img_rows = NP; p.c_row_off = 0; p.ldc = D_VIT;
     p.bias = clsb; p.bias_per_img = 1; p.act = 2;
-    E->exec_macs += (double)NP * D_VIT * D_VIT;
-    E->cat_macs[0] += (double)NP * D_VIT * D_VIT;
+    exec_macs += (double)NP * D_VIT * D_VIT;
+    cat_macs[0] += (double)NP * D_VIT * D_VIT;
     chk(launch_gemm(dt, p, st), "readout", 0);
     if (n == 3) {
-      conv(R, gh, gw, D_VIT, pp + "3.weight", 1, 1, 0, 0, gh, gw, D_VIT, E->a(E->L3), E->f(pp + "3.bias"), 0, 0);
-      tap("l3", E->a(E->L3), gh, gw, D_VIT);
+      conv(R, gh, gw, D_VIT, pp + "3.weight", 1, 1, 0, 0, gh, gw, D_VIT, A(E->L3), E->f(pp + "3.bias"), 0, 0);
+      tap("l3", A(E->L3), gh, gw, D_VIT);
     } else {
-      conv(R, gh, gw, D_VIT, pp + "3.weight", 1, 1, 0, 0, gh, gw, D_VIT, E->a(E->T4), E->f(pp + "3.bias"), 0, 0);
-      conv(E->a(E->T4), gh, gw, D_VIT, pp + "4.weight", 3, 2, 1, 1, h32, w32, D_VIT, E->a(E->L4), E->f(pp + "4.bias"), 0, 0);
-      tap("l4", E->a(E->L4), h32, w32, D_VIT);
+      conv(R, gh, gw, D_VIT, pp + "3.weight", 1, 1, 0, 0, gh, gw, D_VIT, A(E->T4), E->f(pp + "3.bias"), 0, 0);
+      conv(A(E->T4), gh, gw, D_VIT, pp + "4.weight", 3, 2, 1, 1, h32, w32, D_VIT, A(E->L4), E->f(pp + "4.bias"), 0, 0);
+      tap("l4", A(E->L4), h32, w32, D_VIT);
     }
   };
 
   // ---- 12 transformer blocks (timm Block; LN eps 1e-6) -----------------------------------
   for (int l = 0; l < 12; ++l) {
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
-    chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
-    dense(E->a(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, E->a(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0);
-    chk(launch_attention(dt, E->a(E->QKV), E->a(E->AO), B, S, N_HEADS, E->pl, st), "attention", 1);
-    E->exec_macs += 2.0 * N_HEADS * (double)S * S * 64;
-    E->cat_macs[1] += 2.0 * N_HEADS * (double)S * S * 64;
-    dense(E->a(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1);
-    chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), E->a(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln2", 2);
-    dense(E->a(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, E->a(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0);
-    dense(E->a(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1);
+    chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
+    dense(A(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, A(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0);
+    chk(launch_attention(dt, A(E->QKV), A(E->AO), B, S, N_HEADS, E->pl, st), "attention", 1);
+    exec_macs += 2.0 * N_HEADS * (double)S * S * 64;
+    cat_macs[1] += 2.0 * N_HEADS * (double)S * S * 64;
+    dense(A(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1);
+    chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln2", 2);
+    dense(A(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, A(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0);
+    dense(A(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1);
     {
       char nm[16];
       snprintf(nm, sizeof nm, "blk%d", l);
@@ -623,15 +641,15 @@ int Run::forward(const float* x, float* y, float* y2) {
   // on the same encoder outputs (S[0], S[1], L3, L4 are not modified by a decoder)
   auto decode = [&](const std::string& pre, int ch, float* yout) {
   // ---- scratch.layerN_rn (3x3, no bias) ---------------------------------------------------
-  const void* rn_in[4] = {E->a(E->S[0]), E->a(E->S[1]), E->a(E->L3), E->a(E->L4)};
+  const void* rn_in[4] = {A(E->S[0]), A(E->S[1]), A(E->L3), A(E->L4)};
   const int rn_h[4] = {h4, Hi / 8, gh, h32};
   const int rn_w[4] = {w4, Wi / 8, gw, w32};
   const int rn_c[4] = {256, 512, 768, 768};
   const char* rn_names[4] = {"l1_rn", "l2_rn", "l3_rn", "l4_rn"};
   for (int i = 0; i < 4; ++i) {
     conv(rn_in[i], rn_h[i], rn_w[i], rn_c[i], pre + "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
-         rn_w[i], FEAT, E->a(E->lrn[i]), nullptr, 0, 0);
-    tap((pre + rn_names[i]).c_str(), E->a(E->lrn[i]), rn_h[i], rn_w[i], FEAT);
+         rn_w[i], FEAT, A(E->lrn[i]), nullptr, 0, 0);
+    tap((pre + rn_names[i]).c_str(), A(E->lrn[i]), rn_h[i], rn_w[i], FEAT);
   }
 
   // ---- RefineNet fusion 4 -> 1 (blocks.py:320-341).  out_conv (1x1) is applied BEFORE the x2
@@ -644,39 +662,39 @@ int Run::forward(const float* x, float* y, float* y2) {
     const int h = rn_h[i - 1], w = rn_w[i - 1];
     const void* sum;
     if (i == 4) {
-      sum = E->a(E->lrn[3]);
+      sum = A(E->lrn[3]);
     } else {
-      rcu(p + "resConfUnit1.", E->a(E->lrn[i - 1]), h, w, E->a(E->tA), E->a(E->tB), path);  // tB = path + RCU1(lrn)
-      sum = E->a(E->tB);
+      rcu(p + "resConfUnit1.", A(E->lrn[i - 1]), h, w, A(E->tA), A(E->tB), path);  // tB = path + RCU1(lrn)
+      sum = A(E->tB);
     }
-    rcu(p + "resConfUnit2.", sum, h, w, E->a(E->tA), E->a(E->tC), nullptr);
-    conv(E->a(E->tC), h, w, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, w, FEAT, E->a(E->tA), E->f(p + "out_conv.bias"), 0, 0);
-    chk(launch_upsample2x(dt, E->a(E->tA), E->a(E->P[i - 1]), B, h, w, FEAT, E->pl, st), "fusion.up");
-    path = E->a(E->P[i - 1]);
+    rcu(p + "resConfUnit2.", sum, h, w, A(E->tA), A(E->tC), nullptr);
+    conv(A(E->tC), h, w, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, w, FEAT, A(E->tA), E->f(p + "out_conv.bias"), 0, 0);
+    chk(launch_upsample2x(dt, A(E->tA), A(E->P[i - 1]), B, h, w, FEAT, E->pl, st), "fusion.up");
+    path = A(E->P[i - 1]);
     tap((pre + p_names[i - 1]).c_str(), path, 2 * h, 2 * w, FEAT);
   }
 
   // ---- head (dpt_depth.py:91-99) ----------------------------------------------------------
   const std::string oc = pre + "scratch.output_conv.";
-  conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, E->a(E->H0), E->f(oc + "0.bias"), 0, 0);
-  tap((pre + "h0").c_str(), E->a(E->H0), h2, w2, 128);
+  conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, A(E->H0), E->f(oc + "0.bias"), 0, 0);
+  tap((pre + "h0").c_str(), A(E->H0), h2, w2, 128);
   if (E->head_fused()) {
     // x2 upsample + conv 128->32 + ReLU + conv 1x1 + ReLU in one launch (head.hip): the 37.7 MB/image up-sampled map
     // and the 32-channel map never reach memory.  Not in bf16x3 mode, and not while stage taps are recorded ("h1").
-    chk(launch_head_tail(dt, E->a(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"), E->f(oc + "4.weight"), E->f(oc + "4.bias"),
+    chk(launch_head_tail(dt, A(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"), E->f(oc + "4.weight"), E->f(oc + "4.bias"),
                          yout, B, h2, w2, ch, E->cfg.non_negative, st),
         "head.tail", 0);
-    E->exec_macs += (double)Hi * Wi * 32 * 1152;
-    E->cat_macs[0] += (double)Hi * Wi * 32 * (1152 + ch);
+    exec_macs += (double)Hi * Wi * 32 * 1152;
+    cat_macs[0] += (double)Hi * Wi * 32 * (1152 + ch);
   } else {
-    chk(launch_upsample2x(dt, E->a(E->H0), E->a(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
-    conv(E->a(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, E->a(E->H1), E->f(oc + "2.bias"), 1, 0);
-    tap((pre + "h1").c_str(), E->a(E->H1), Hi, Wi, 32);
-    chk(launch_head_out(dt, E->a(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, B, Hi * Wi, ch,
+    chk(launch_upsample2x(dt, A(E->H0), A(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
+    conv(A(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, A(E->H1), E->f(oc + "2.bias"), 1, 0);
+    tap((pre + "h1").c_str(), A(E->H1), Hi, Wi, 32);
+    chk(launch_head_out(dt, A(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, B, Hi * Wi, ch,
                         E->cfg.non_negative, E->pl, st),
         "head.out");
   }
-  E->exec_macs += (double)Hi * Wi * 32 * ch;
+  exec_macs += (double)Hi * Wi * 32 * ch;
   };
   decode("", E->cfg.num_channels, y);
   if (E->cfg.dual_task) {
@@ -685,7 +703,6 @@ int Run::forward(const float* x, float* y, float* y2) {
     for (const char* n : {"l1_rn", "l2_rn", "l3_rn", "l4_rn", "p1", "p2", "p3", "p4", "h0", "h1"}) E->taps.erase(n);
     decode("depth.", 1, y2);
   }
-  E->last_batch = B;
   if (err != hipSuccess) return E->fail(DPTX_E_HIP, std::string("launch failed at ") + where + ": " + hipGetErrorString(err));
   return DPTX_OK;
 }
@@ -716,6 +733,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   const int max_h = cfg->max_height ? cfg->max_height : IMG, max_w = cfg->max_width ? cfg->max_width : IMG;
   if (max_h < 64 || max_w < 64 || max_h % 32 != 0 || max_w % 32 != 0 || max_h > 4096 || max_w > 4096) return DPTX_E_INVALID;
   if ((long long)cfg->max_batch * max_h * max_w * 256 >= (1ll << 31)) return DPTX_E_INVALID;  // = max_batch <= 56 at 384x384
+  if (cfg->streams < 0 || cfg->streams > 2) return DPTX_E_INVALID;
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16 && cfg->dtype != DPTX_DTYPE_BF16X3) ||
@@ -725,6 +743,11 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (!e) return DPTX_E_ALLOC;
   e->cfg = *cfg;
   e->max_h = max_h;
+  {
+    const char* t = getenv("DPTX_STREAMS");  // experiments: overrides cfg.streams
+    const int ns = t ? atoi(t) : cfg->streams;
+    e->n_streams = ns == 1 ? 1 : 2;
+  }
   e->max_w = max_w;
   e->tok_tap_stride = (size_t)cfg->max_batch * ((size_t)max_h * max_w / 256 + 1) * D_VIT;
   e->spec = build_spec(cfg->num_channels, cfg->dual_task != 0);
@@ -761,6 +784,11 @@ void dptx_destroy(dptx_handle h) {
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
     for (auto ev : h->events) (void)hipEventDestroy(ev);
+    for (int r = 0; r < 2; ++r) {
+      if (h->sub_stream[r]) (void)hipStreamDestroy(h->sub_stream[r]);
+      if (h->ev_join[r]) (void)hipEventDestroy(h->ev_join[r]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   }
   delete h;
 }
@@ -846,6 +874,57 @@ int dptx_enable_taps(dptx_handle h, int on) {
   return DPTX_OK;
 }
 
+// Runs one forward: either one Run over the whole batch on the caller's stream, or -- two streams, no taps, no per-launch
+// timing, batch >= 2 -- two Runs over the two halves of the batch on the handle's two internal streams, forked from and
+// joined to the caller's stream with events.  Images are independent and every kernel is batch-invariant bit for bit, so
+// both schedules return the same bits; the second one lets the MFMA-bound launches of one half overlap the HBM-bound
+// launches and the tails of the other.
+static int run_forward(dptx_handle h, const float* x, float* y, float* y2, int batch, int height, int width, hipStream_t stream) {
+  const int C = h->cfg.num_channels;
+  const bool split = h->n_streams == 2 && batch >= 2 && !h->taps_on && !h->profiling;
+  if (!split) {
+    Run run{h, batch, stream, h->cfg.dtype, height, width};
+    const int rc = run.forward(x, y, y2);
+    h->launches = run.launches;
+    h->exec_macs = run.exec_macs;
+    for (int c = 0; c < 4; ++c) h->cat_macs[c] = run.cat_macs[c];
+    h->last_batch = batch;
+    return rc;
+  }
+  if (!h->ev_fork) {
+    for (int r = 0; r < 2; ++r) {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[r], hipEventDisableTiming));
+    }
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  }
+  HIPCHK(h, hipEventRecord(h->ev_fork, stream));
+  const int n0 = (batch + 1) / 2;
+  const size_t px = (size_t)height * width;
+  int rc = DPTX_OK;
+  int64_t launches = 0;
+  for (int r = 0; r < 2; ++r) {
+    const int nb = r == 0 ? n0 : batch - n0;
+    const size_t first = r == 0 ? 0 : (size_t)n0;
+    HIPCHK(h, hipStreamWaitEvent(h->sub_stream[r], h->ev_fork, 0));
+    Run run{h, nb, h->sub_stream[r], h->cfg.dtype, height, width};
+    run.abase = (size_t)r * h->half_region;
+    run.half = true;
+    const int rr = run.forward(x + first * 3 * px, y + first * C * px, y2 ? y2 + first * px : nullptr);
+    if (rc == DPTX_OK) rc = rr;
+    launches += run.launches;
+    if (r == 0) {
+      h->exec_macs = run.exec_macs;
+      for (int c = 0; c < 4; ++c) h->cat_macs[c] = run.cat_macs[c];
+    }
+    HIPCHK(h, hipEventRecord(h->ev_join[r], h->sub_stream[r]));
+    HIPCHK(h, hipStreamWaitEvent(stream, h->ev_join[r], 0));
+  }
+  h->launches = launches;
+  h->last_batch = batch;
+  return rc;
+}
+
 int dptx_forward(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, int32_t batch, void* stream) {
   return dptx_forward_hw(h, x_dev, x_dtype, y_dev, batch, IMG, IMG, stream);
 }
@@ -863,8 +942,7 @@ int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_d
   if ((long long)height * width > (long long)h->max_h * h->max_w)
     return h->fail(DPTX_E_INVALID, "input larger than the engine was planned for (dptx_config.max_height/max_width)");
   if (h->cfg.dual_task) return h->fail(DPTX_E_INVALID, "dual-task handle: call dptx_forward_dual");
-  Run run{h, batch, (hipStream_t)stream, h->cfg.dtype, height, width};
-  return run.forward((const float*)x_dev, (float*)y_dev, nullptr);
+  return run_forward(h, (const float*)x_dev, (float*)y_dev, nullptr, batch, height, width, (hipStream_t)stream);
 }
 
 int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_normal_dev, void* y_depth_dev, int32_t batch,
@@ -880,8 +958,7 @@ int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y
   if ((long long)height * width > (long long)h->max_h * h->max_w)
     return h->fail(DPTX_E_INVALID, "input larger than the engine was planned for (dptx_config.max_height/max_width)");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  Run run{h, batch, (hipStream_t)stream, h->cfg.dtype, height, width};
-  return run.forward((const float*)x_dev, (float*)y_normal_dev, (float*)y_depth_dev);
+  return run_forward(h, (const float*)x_dev, (float*)y_normal_dev, (float*)y_depth_dev, batch, height, width, (hipStream_t)stream);
 }
 
 int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_floats, int64_t shape4[4]) {

@@ -21,7 +21,7 @@ class DptxConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32),
                 ("device_id", C.c_int32), ("non_negative", C.c_int32), ("ws_form", C.c_int32),
                 ("ws_eps", C.c_float), ("max_height", C.c_int32), ("max_width", C.c_int32),
-                ("dual_task", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("dual_task", C.c_int32), ("streams", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 # (name, restype, argtypes) for every symbol declared in include/dptx.h
@@ -95,7 +95,7 @@ class Engine:
 
     def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "bf16",
                  device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8,
-                 max_hw: Tuple[int, int] = (384, 384), dual: bool = False):
+                 max_hw: Tuple[int, int] = (384, 384), dual: bool = False, streams: int = 0):
         self.lib = load_library()
         cfg = DptxConfig()
         self.lib.dptx_default_config(C.byref(cfg))
@@ -104,6 +104,7 @@ class Engine:
         cfg.non_negative, cfg.ws_form, cfg.ws_eps = int(non_negative), ws_form, ws_eps
         cfg.max_height, cfg.max_width = int(max_hw[0]), int(max_hw[1])
         cfg.dual_task = int(dual)
+        cfg.streams = int(streams)
         self.cfg = cfg
         self.dtype = dtype
         self.h = _vp()

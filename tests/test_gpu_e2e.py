@@ -158,12 +158,35 @@ def test_fused_head_equals_unfused(dtype):
     x = synthetic_input(3, 2, "normal").to(DEV)
     y_fused = model(x).clone()
     eng = model.engine
-    launches_fused = eng.info()[0]
+    launches_fused = eng.info()[0]  # two half-batch runs on two streams
     eng.enable_taps(True)
-    y_unfused = model(x).clone()
-    assert eng.info()[0] == launches_fused + 2
+    y_unfused = model(x).clone()      # taps: one run over the whole batch, three launches instead of one for the head tail
+    assert launches_fused == 2 * (eng.info()[0] - 2)
     eng.enable_taps(False)
     d = (y_fused - y_unfused).abs().max().item()
     print(f"\n[{dtype}] fused vs unfused head tail: max|d| = {d:.3e}")
     assert d < (4e-3 if dtype == "bf16" else 5e-4)  # half a 16-bit ulp of h1 (|h1| ~ 1) times sum|w4| ~ 1
     assert torch.equal(model(x), y_fused)
+
+
+def test_two_stream_split_is_bit_identical():
+    """dptx_config.streams: two half-batches on two internal streams (default) against everything on the caller's stream."""
+    from omnidata_amd.engine import Engine
+    sd = random_state_dict(0, 3)
+    x = synthetic_input(5, 7, "normal").to(DEV)
+    outs = []
+    for streams in (1, 2):
+        eng = Engine(num_channels=3, max_batch=7, dtype="bf16", device_id=0, streams=streams)
+        eng.load_state_dict(sd)
+        y = eng.forward(x).clone()
+        side = torch.cuda.Stream()   # and from a non-default caller stream
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.current_stream())
+            y2 = eng.forward(x[:5]).clone()
+        side.synchronize()
+        assert torch.equal(y2, y[:5])
+        outs.append(y)
+        n, _, _ = eng.info()
+        assert (n > 400) == (streams == 2)
+        eng.close()
+    assert torch.equal(outs[0], outs[1])
