@@ -587,6 +587,7 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (experiments)
   if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
   {
+    if (forced == 128128 && p.N % 128 == 0) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
     if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
     if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
   }
@@ -602,7 +603,9 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
     if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= min_k && t256 >= 200 && t256 * 100 >= rounds * 256 * 85)
       return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
   }
-  if (p.N % 128 == 0 && m128 * (p.N / 128) >= 448) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
+  // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
+  // 128x64 by 2..10 %, whose second round is nearly empty
+  if (p.N % 128 == 0 && m128 * (p.N / 128) >= 256) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
   if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1>(p, stream);
   if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 256, 64, 4, 1>(p, stream);
   if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
