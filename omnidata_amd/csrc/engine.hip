@@ -463,6 +463,15 @@ struct Run {
     chk(launch_gn_apply(dt, g, e->pl, st), nkey.c_str(), 2);
   }
 
+  // GroupNorm (+ plain residual, + ReLU) in place: statistics launch + apply launch.  (A single-launch variant that held
+  // a 64-channel slab of a small map in registers was measured at +0.7 % end to end and removed: reading the output of
+  // the preceding GEMM it returned stale values in ~1 % of launches whenever a second stream kept the GPU busy --
+  // profiles/r01_experiments.md.)
+  void gn(void* X, const std::string& nkey, float* part, int HW, int C, int relu, const void* R = nullptr) {
+    gn_stats(X, part, HW, C);
+    gn_apply(X, nkey, part, HW, C, relu, R);
+  }
+
   // RCU (blocks.py:263-286): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
   void rcu(const std::string& p, const void* x, int H, int W, void* tmp, void* out, const void* extra) {
     conv(x, H, W, FEAT, p + "conv1.weight", 3, 1, 1, 1, H, W, FEAT, tmp, e->f(p + "conv1.bias"), /*act*/ 1, /*a_relu*/ 1);
@@ -525,19 +534,18 @@ int Run::forward(const float* x, float* y, float* y2) {
         gn_stats(A(E->DS), part3, Ho * Wo, cout);
       }
       conv(cur, H, Wd, cin, p + "conv1.weight", 1, 1, 0, 0, H, Wd, mid, A(E->T1), nullptr, 0, 0);
-      gn_stats(A(E->T1), part0, H * Wd, mid);
-      gn_apply(A(E->T1), p + "norm1", part0, H * Wd, mid, 1);
+      gn(A(E->T1), p + "norm1", part0, H * Wd, mid, 1);
       // 3x3, stride on conv2 (V1.5); TF-SAME: s1 -> pad (1,1); s2 on even H -> pad (0,1)
       const int pad = (stride == 1) ? 1 : 0;
       conv(A(E->T1), H, Wd, mid, p + "conv2.weight", 3, stride, pad, pad, Ho, Wo, mid, A(E->T2), nullptr, 0, 0);
-      gn_stats(A(E->T2), part1, Ho * Wo, mid);
-      gn_apply(A(E->T2), p + "norm2", part1, Ho * Wo, mid, 1);
+      gn(A(E->T2), p + "norm2", part1, Ho * Wo, mid, 1);
       conv(A(E->T2), Ho, Wo, mid, p + "conv3.weight", 1, 1, 0, 0, Ho, Wo, cout, out, nullptr, 0, 0);
-      gn_stats(out, part2, Ho * Wo, cout);
-      if (b == 0)
+      if (b == 0) {
+        gn_stats(out, part2, Ho * Wo, cout);
         gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, A(E->DS), p + "downsample.norm", part3);
-      else
-        gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, cur);
+      } else {
+        gn(out, p + "norm3", part2, Ho * Wo, cout, 1, cur);
+      }
       cur = out;
       H = Ho;
       Wd = Wo;
@@ -1089,6 +1097,7 @@ int dptx_op_layernorm(int32_t dtype, const float* x, const float* gamma, const f
 
 int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const float* beta, const void* R, void* Y, int32_t B,
                       int32_t HW, int32_t C, int32_t relu, float eps, void* scratch_f32, void* stream) {
+  if (scratch_f32 == nullptr) return DPTX_E_INVALID;
   hipError_t r = launch_gn_stats(dtype, X, (float*)scratch_f32, B, HW, C, g_op_planes, (hipStream_t)stream);
   if (r != hipSuccess) return DPTX_E_HIP;
   GnParams g{};
