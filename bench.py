@@ -190,7 +190,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic 384x384 inputs resident in HBM; seeded random weights",
             "config": {"workload": f"DPT-Hybrid-384 {args.task}, batch {args.batch}/GPU, {args.dtype}, {world}xMI355X "
                                    f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"replicas x{world} (no collective in the loop)"},
+                       "parallelism": f"replicas x{world} (no collective in the loop)",
+                       "schedule": "each forward = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)"},
             "e2e_mfma_frac": round(e2e_tflops / (PEAK_TFLOPS * world), 4),
             "e2e_tflops_algorithmic": round(e2e_tflops, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernel_breakdown": breakdown,
