@@ -161,6 +161,31 @@ class Engine:
         self._check(self.lib.dptx_import_packed_device(self.h, blob.data_ptr(), blob.numel(), _stream()), "import_packed_device")
         torch.cuda.current_stream().synchronize()
 
+    # ---- packed-blob cache on disk: skips the fp32 fold / re-layout / upload-from-fp32 at start-up
+    def _cache_meta(self) -> Dict[str, str]:
+        c = self.cfg
+        return {"format": "dptx-packed-v1", "library": self.lib.dptx_version().decode(), "dtype": self.dtype,
+                "num_channels": str(c.num_channels), "dual_task": str(c.dual_task), "ws_form": str(c.ws_form),
+                "ws_eps": repr(float(c.ws_eps)), "packed_bytes": str(self.packed_bytes)}
+
+    def save_packed(self, path: str):
+        """Writes the packed weight blob (what ranks exchange at start-up) as a safetensors file."""
+        from safetensors.torch import save_file
+        blob = torch.from_numpy(self.export_packed_host())
+        save_file({"blob": blob}, path, metadata=self._cache_meta())
+
+    def load_packed(self, path: str):
+        """Loads a blob written by save_packed into this (device) engine; refuses blobs of another configuration."""
+        from safetensors import safe_open
+        with safe_open(path, framework="pt", device="cpu") as f:
+            meta = f.metadata() or {}
+            want = self._cache_meta()
+            bad = {k: (meta.get(k), v) for k, v in want.items() if meta.get(k) != v}
+            if bad:
+                raise RuntimeError(f"packed-weight cache {path} does not match this engine: {bad}")
+            blob = f.get_tensor("blob")
+        self.import_packed(blob.to(f"cuda:{self.cfg.device_id}"))
+
     # ---- compute
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not x.is_cuda:

@@ -192,3 +192,17 @@ def test_two_stream_split_is_bit_identical():
         assert (n > 400) == (streams == 2)
         eng.close()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_packed_blob_cache_roundtrip(tmp_path):
+    """save_packed on one engine, load_packed into a fresh one: same forward, no fp32 weights needed."""
+    from omnidata_amd.engine import Engine
+    sd = random_state_dict(4, 1)
+    a = Engine(num_channels=1, max_batch=2, dtype="bf16", device_id=0)
+    a.load_state_dict(sd)
+    path = str(tmp_path / "depth.safetensors")
+    a.save_packed(path)
+    b = Engine(num_channels=1, max_batch=2, dtype="bf16", device_id=0)
+    b.load_packed(path)
+    x = synthetic_input(1, 2, "depth").to(DEV)
+    assert torch.equal(a.forward(x), b.forward(x))

@@ -151,3 +151,45 @@ def test_dual_task_spec_and_packing():
     assert (blob[:one.packed_bytes] == one.export_packed_host()).all()
     with pytest.raises(RuntimeError):
         Engine(num_channels=1, max_batch=1, device_id=None, dual=True)  # dual needs the 3-channel primary
+
+
+def test_metrics_match_reference_golden():
+    """omnidata_amd/metrics.py against numbers produced by the reference's paper_code/evaluation_metrics.py
+    (oracle/validate_metrics_vs_reference.py; inputs are regenerated from the seed)."""
+    import glob
+    from omnidata_amd.metrics import get_metrics
+    from oracle.validate_metrics_vs_reference import make_case
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "metrics_*.npz")))
+    assert len(files) == 4
+    for f in files:
+        g = np.load(f)
+        task = "normal" if "metrics_normal" in f else "depth_zbuffer"
+        seed = int(f.split("seed")[1].split(".")[0])
+        p, t, m = make_case(seed, task)
+        got = get_metrics(p, t, task=task, masks=m)
+        for k, v in zip(g["keys"], g["values"]):
+            assert abs(got[str(k)] - v) <= 1e-6 * max(1.0, abs(v)), (f, k)
+    # degenerate inputs
+    p, t, m = make_case(0, "normal")
+    assert get_metrics(p, t, task="normal", masks=torch.zeros_like(m)) is None
+    same = get_metrics(t, t, task="normal", masks=m)
+    assert same["ang_error_mean"] < 1e-3 and same["percentage_within_11.25_degrees"] == 1.0
+
+
+def test_packed_blob_cache_file(tmp_path):
+    """Engine.save_packed: the safetensors file holds exactly the packed blob + the configuration it belongs to."""
+    from safetensors import safe_open
+    from omnidata_amd.engine import Engine
+    eng = Engine(num_channels=1, max_batch=1, dtype="fp16", device_id=None)
+    eng.load_state_dict(random_state_dict(3, 1))
+    path = str(tmp_path / "w.safetensors")
+    eng.save_packed(path)
+    with safe_open(path, framework="pt", device="cpu") as f:
+        meta = f.metadata()
+        blob = f.get_tensor("blob")
+    assert meta["format"] == "dptx-packed-v1" and meta["dtype"] == "fp16" and meta["num_channels"] == "1"
+    assert int(meta["packed_bytes"]) == blob.numel() == eng.packed_bytes
+    assert (blob.numpy() == eng.export_packed_host()).all()
+    other = Engine(num_channels=3, max_batch=1, dtype="fp16", device_id=None)
+    with pytest.raises(RuntimeError, match="does not match this engine"):
+        other.load_packed(path)
