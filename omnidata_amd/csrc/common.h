@@ -166,7 +166,7 @@ __device__ __forceinline__ float bilerp(float a, float b, float c, float d, floa
 
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));  // v_rcp_f32 (1 ulp); __frcp_rn expands to a full division
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float e = fmaf(-poly, __expf(-z * z), 1.0f);
   return 0.5f * x * (1.0f + copysignf(e, x));
