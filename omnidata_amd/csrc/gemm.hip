@@ -155,8 +155,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   for (int row = rr; row < CT_ROWS; row += RPP) {
     const int m = m0 + (SLABS == 1 ? row : (row >> 5) * (TM * 32) + s * 32 + (row & 31));
     if (m >= p.M) break;
-    const int img = m / p.c_rpi;
-    const int pp = m - img * p.c_rpi;
+    // token-row remap (patch-embed, readout): image / row-in-image of GEMM row m; everything else has c_rpi = INT_MAX
+    // and skips the integer division (a uniform branch; ~30 VALU instructions per row otherwise)
+    int img = 0, pp = m;
+    if (p.c_rpi != 0x7fffffff) {
+      img = m / p.c_rpi;
+      pp = m - img * p.c_rpi;
+    }
     const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
     float v[8];
     {
