@@ -134,8 +134,9 @@ int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y
 /* Debug hook for stage-level parity (SURVEY.md A.1 tap names: "stem","s0","s1","s2","tok0",
  * "blk0".."blk11","l3","l4","l1_rn".."l4_rn","p4","p3","p2","p1","h0","h1").  Copies the
  * stage activation of the LAST forward, converted to fp32 in the engine's internal layout
- * (NHWC for feature maps, [batch*577,768] for tokens), to dst_host.  *shape4 receives
- * {batch, H, W, C} (or {batch,577,768,1}).  Returns DPTX_E_KEY for unknown names. */
+ * (NHWC for feature maps, [batch*S,768] for tokens; S = (H/16)*(W/16)+1 = 577 at 384x384), to dst_host.  *shape4
+ * receives {batch, H, W, C} (or {batch,S,768,1}).  Returns DPTX_E_KEY for unknown names.  Taps make the forward run
+ * as one pass over the whole batch on the caller's stream and keep the three-launch head tail (so "h1" exists). */
 int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_floats,
              int64_t shape4[4]);
 /* The fp32 token stream is updated in place by the 12 blocks; "tok0"/"blkN" taps therefore need

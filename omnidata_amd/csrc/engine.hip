@@ -234,7 +234,7 @@ struct dptx_engine {
     return env == 1 && cfg.dtype != DPTX_DTYPE_BF16X3 && !taps_on;
   }
   size_t tok_tap_stride = 0;      // floats per token-stream snapshot
-  float* d_tok_taps = nullptr;  // [13][B*577*768] fp32 copies of the token stream (taps_on)
+  float* d_tok_taps = nullptr;  // [13][max_batch*(max tokens)*768] fp32 copies of the token stream (taps_on)
   int64_t launches = 0;
   double exec_macs = 0.0;
   int last_batch = 0;
@@ -255,7 +255,6 @@ struct dptx_engine {
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   // arena slices
   int max_h = 384, max_w = 384;   // largest supported input (cfg.max_height/max_width; 0 = 384)
-  int pos_gh = 0, pos_gw = 0;     // grid of the resized pos_embed currently held in pos_alt
   Buf pos_alt;
   Buf sraw, stem, S[3], T1, T2, PA, PB, DS, part[4], X, Hn, QKV, AO, F1, R3, R4, L3, T4, L4, clsb, lrn[4], tA, tB,
       tC, P[4], H0, H0U, H1;
@@ -266,7 +265,6 @@ struct dptx_engine {
   }
   const void* w(const std::string& key) const { return d_blob + packed_off.at(key); }
   const float* f(const std::string& key) const { return (const float*)(d_blob + packed_off.at(key)); }
-  char* a(const Buf& b) const { return d_arena + b.off; }
 };
 
 namespace {
@@ -555,7 +553,7 @@ int Run::forward(const float* x, float* y, float* y2) {
     tap(names[s], cur, H, Wd, cout);
   }
 
-  // ---- tokens: 1x1 proj + bias + pos_embed -> fp32 stream X[b*577 + 1 + p]; cls rows ----
+  // ---- tokens: 1x1 proj + bias + pos_embed -> fp32 stream X[b*S + 1 + p] (S = 577 at 384x384); cls rows ----
   float* X = (float*)A(E->X);
   {
     GemmParams p;

@@ -220,7 +220,7 @@ class Engine:
         self._check(self.lib.dptx_enable_taps(self.h, int(on)), "enable_taps")
 
     def tap(self, name: str) -> torch.Tensor:
-        """Stage activation of the last forward as an fp32 CPU tensor in NCHW ([B,577,768] for tokens)."""
+        """Stage activation of the last forward as an fp32 CPU tensor in NCHW ([B,S,768] for tokens; S = 577 at 384x384)."""
         shape = (C.c_int64 * 4)()
         probe = np.empty(1, dtype=np.float32)
         rc = self.lib.dptx_tap(self.h, name.encode(), probe.ctypes.data, 0, shape)  # size query
