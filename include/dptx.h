@@ -56,8 +56,8 @@ typedef struct dptx_config {
   int32_t max_height;    /* largest input the arena is planned for; 0 = 384. Multiples of 32,   */
   int32_t max_width;     /*   >= 64, and max_batch*max_height*max_width*256 < 2^31 (see dptx_forward_hw) */
   int32_t dual_task;     /* 1: two decoders on one shared encoder (see dptx_forward_dual); needs num_channels = 3 */
-  int32_t streams;       /* 0 or 2: a forward of >= 2 images runs as two half-batches on two internal streams,   */
-                         /*   forked from / joined to the caller's stream (same bits, ~3 % faster); 1: caller's stream only */
+  int32_t streams;       /* n = 2..4 (0 = 2): a forward of >= 2 images runs as n sub-batches on n internal streams, */
+                         /*   forked from / joined to the caller's stream (same bits, faster); 1: caller's stream only */
   int32_t reserved[4];   /* must be zero                                                        */
 } dptx_config;
 

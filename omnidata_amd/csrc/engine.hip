@@ -248,11 +248,12 @@ struct dptx_engine {
   double cat_macs[4] = {0, 0, 0, 0};
 
   // two sub-batches on two internal streams (MFMA-bound and HBM-bound launches of the two halves overlap, tails fill)
+  static constexpr int MAX_STREAMS = 4;
   int n_streams = 2;              // cfg.streams (0 = default 2); 1 = everything on the caller's stream
-  int half_batch = 0;             // images per half-batch region
-  size_t half_region = 0;         // bytes of one half-batch region (two of them fit in one arena plane)
-  hipStream_t sub_stream[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  int half_batch = 0;             // images per sub-batch region (ceil(max_batch / n_streams))
+  size_t half_region = 0;         // bytes of one sub-batch region (n_streams of them fit in one arena plane)
+  hipStream_t sub_stream[MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   // arena slices
   int max_h = 384, max_w = 384;   // largest supported input (cfg.max_height/max_width; 0 = 384)
   Buf pos_alt;
@@ -325,9 +326,10 @@ size_t plan_arena_for(dptx_engine* e, size_t B, bool half) {
 
 void plan_arena(dptx_engine* e) {
   const size_t full = plan_arena_for(e, (size_t)e->cfg.max_batch, false);
-  e->half_batch = (e->cfg.max_batch + 1) / 2;
+  const int ns = e->n_streams > 1 ? e->n_streams : 2;
+  e->half_batch = (e->cfg.max_batch + ns - 1) / ns;
   e->half_region = align_up(plan_arena_for(e, (size_t)e->half_batch, true), 256);
-  const size_t off = std::max(full, 2 * e->half_region);
+  const size_t off = std::max(full, (size_t)ns * e->half_region);
   e->arena_single = off;
   const int npl = e->cfg.dtype == DPTX_DTYPE_BF16X3 ? 2 : 1;
   e->arena_bytes = off * npl;
@@ -739,7 +741,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   const int max_h = cfg->max_height ? cfg->max_height : IMG, max_w = cfg->max_width ? cfg->max_width : IMG;
   if (max_h < 64 || max_w < 64 || max_h % 32 != 0 || max_w % 32 != 0 || max_h > 4096 || max_w > 4096) return DPTX_E_INVALID;
   if ((long long)cfg->max_batch * max_h * max_w * 256 >= (1ll << 31)) return DPTX_E_INVALID;  // = max_batch <= 56 at 384x384
-  if (cfg->streams < 0 || cfg->streams > 2) return DPTX_E_INVALID;
+  if (cfg->streams < 0 || cfg->streams > 4) return DPTX_E_INVALID;
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16 && cfg->dtype != DPTX_DTYPE_BF16X3) ||
@@ -752,7 +754,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   {
     const char* t = getenv("DPTX_STREAMS");  // experiments: overrides cfg.streams
     const int ns = t ? atoi(t) : cfg->streams;
-    e->n_streams = ns == 1 ? 1 : 2;
+    e->n_streams = ns == 0 ? 2 : (ns < 1 ? 1 : (ns > dptx_engine::MAX_STREAMS ? dptx_engine::MAX_STREAMS : ns));
   }
   e->max_w = max_w;
   e->tok_tap_stride = (size_t)cfg->max_batch * ((size_t)max_h * max_w / 256 + 1) * D_VIT;
@@ -790,7 +792,7 @@ void dptx_destroy(dptx_handle h) {
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
     for (auto ev : h->events) (void)hipEventDestroy(ev);
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
       if (h->sub_stream[r]) (void)hipStreamDestroy(h->sub_stream[r]);
       if (h->ev_join[r]) (void)hipEventDestroy(h->ev_join[r]);
     }
@@ -887,7 +889,7 @@ int dptx_enable_taps(dptx_handle h, int on) {
 // launches and the tails of the other.
 static int run_forward(dptx_handle h, const float* x, float* y, float* y2, int batch, int height, int width, hipStream_t stream) {
   const int C = h->cfg.num_channels;
-  const bool split = h->n_streams == 2 && batch >= 2 && !h->taps_on && !h->profiling;
+  const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling;
   if (!split) {
     Run run{h, batch, stream, h->cfg.dtype, height, width};
     const int rc = run.forward(x, y, y2);
@@ -897,21 +899,21 @@ static int run_forward(dptx_handle h, const float* x, float* y, float* y2, int b
     h->last_batch = batch;
     return rc;
   }
+  const int nr = batch < h->n_streams ? batch : h->n_streams;  // sub-batches: the first (batch % nr) get one image more
   if (!h->ev_fork) {
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
       HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));
       HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[r], hipEventDisableTiming));
     }
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   }
   HIPCHK(h, hipEventRecord(h->ev_fork, stream));
-  const int n0 = (batch + 1) / 2;
   const size_t px = (size_t)height * width;
   int rc = DPTX_OK;
   int64_t launches = 0;
-  for (int r = 0; r < 2; ++r) {
-    const int nb = r == 0 ? n0 : batch - n0;
-    const size_t first = r == 0 ? 0 : (size_t)n0;
+  size_t first = 0;
+  for (int r = 0; r < nr; ++r) {
+    const int nb = batch / nr + (r < batch % nr ? 1 : 0);
     HIPCHK(h, hipStreamWaitEvent(h->sub_stream[r], h->ev_fork, 0));
     Run run{h, nb, h->sub_stream[r], h->cfg.dtype, height, width};
     run.abase = (size_t)r * h->half_region;
@@ -925,6 +927,7 @@ static int run_forward(dptx_handle h, const float* x, float* y, float* y2, int b
     }
     HIPCHK(h, hipEventRecord(h->ev_join[r], h->sub_stream[r]));
     HIPCHK(h, hipStreamWaitEvent(stream, h->ev_join[r], 0));
+    first += (size_t)nb;
   }
   h->launches = launches;
   h->last_batch = batch;
