@@ -193,3 +193,21 @@ def test_packed_blob_cache_file(tmp_path):
     other = Engine(num_channels=3, max_batch=1, dtype="fp16", device_id=None)
     with pytest.raises(RuntimeError, match="does not match this engine"):
         other.load_packed(path)
+
+
+def test_config_validation_and_arena_scaling():
+    """dptx_create rejects configurations it cannot serve; the arena scales with max_height x max_width (host-only handles)."""
+    from omnidata_amd.engine import Engine
+    base = Engine(num_channels=3, max_batch=4, device_id=None)
+    big = Engine(num_channels=3, max_batch=4, device_id=None, max_hw=(512, 640))
+    ratio = (big.workspace_bytes - big.packed_bytes) / (base.workspace_bytes - base.packed_bytes)
+    assert 2.1 < ratio < 2.35  # 512*640 / 384^2 = 2.22 (plus the per-buffer alignment)
+    for bad in (dict(max_hw=(400, 384)), dict(max_hw=(32, 384)), dict(streams=5), dict(num_channels=2), dict(max_batch=49),
+                dict(max_batch=48, max_hw=(768, 768))):  # the last one: an activation would pass 2 GB
+        with pytest.raises(RuntimeError, match="dptx_create failed"):
+            Engine(**{**dict(num_channels=3, max_batch=4, device_id=None), **bad})
+    # sub-batch regions of the multi-stream schedule never need more than the whole-batch plan plus alignment slack
+    for ns in (1, 2, 3, 4):
+        e = Engine(num_channels=3, max_batch=7, device_id=None, streams=ns)
+        one = Engine(num_channels=3, max_batch=7, device_id=None, streams=1)
+        assert e.workspace_bytes <= one.workspace_bytes * 1.35
