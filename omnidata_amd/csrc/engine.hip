@@ -447,6 +447,7 @@ struct Run {
     p.ksz = ksz; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
     p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = Cout;
     p.act = act; p.a_relu = a_relu; p.planes = e->pl;
+    p.k_tap_fast = (ksz == 3 && Cin >= 512) ? 1 : 0;  // measured per layer: profiles/r01_experiments.md
     exec_macs += (double)p.M / B * p.N * p.K;
     cat_macs[0] += (double)p.M / B * p.N * p.K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
@@ -1080,6 +1081,7 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
   p.a_bytes = (long long)B * H * W * Cin * 2;
   p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act; p.a_relu = a_relu; p.planes = g_op_planes;
+  p.k_tap_fast = (ksize == 3 && Cin >= 512) ? 1 : 0;
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 

@@ -306,6 +306,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
     char* sa_ = smem + (BUF) * STAGE_BYTES + wave * 1024;                                                          \
     char* sb_ = sa_ + B_BASE;                                                                                      \
     const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
+    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);  /* k = (tap, channel) in W */           \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                         \
       const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
       const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
@@ -318,15 +319,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
     }                                                                                                              \
     _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) {                                                         \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(sb_ + j * PASS_BYTES), 16,   \
-                                               w_off[j] + (unsigned)((K0) * 2), 0, 0, 0);                          \
+                                               w_off[j] + wk_, 0, 0, 0);                                           \
       if (PL == 2)                                                                                                 \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcWl, (__attribute__((address_space(3))) void*)(sb_ + B_LO + j * PASS_BYTES), \
-                                                 16, w_off[j] + (unsigned)((K0) * 2), 0, 0, 0);                    \
+                                                 16, w_off[j] + wk_, 0, 0, 0);                                     \
     }                                                                                                              \
-    c0 += BK;                                                                                                      \
-    if (c0 >= p.Cin) {                                                                                             \
-      c0 = 0;                                                                                                      \
-      if (++kx == p.ksz) { kx = 0; ++ky; }                                                                         \
+    if (p.k_tap_fast) { /* the nine taps re-read the same input lines in nine consecutive k-tiles (L2-resident) */ \
+      if (++kx == p.ksz) {                                                                                         \
+        kx = 0;                                                                                                    \
+        if (++ky == p.ksz) { ky = 0; c0 += BK; }                                                                   \
+      }                                                                                                            \
+    } else { /* channels-fastest inside a tap */                                                                   \
+      c0 += BK;                                                                                                    \
+      if (c0 >= p.Cin) {                                                                                           \
+        c0 = 0;                                                                                                    \
+        if (++kx == p.ksz) { kx = 0; ++ky; }                                                                       \
+      }                                                                                                            \
     }                                                                                                              \
   } while (0)
 
