@@ -121,8 +121,17 @@ def is_unused(key: str) -> bool:
     return key.startswith(UNUSED_KEYS)
 
 
-def _gain_for(key: str, shape) -> Tuple[str, float]:
-    """Returns (kind, scale) for the synthetic init of one tensor."""
+FAMILIES = ("default", "trained")
+
+
+def _gain_for(key: str, shape, family: str = "default") -> Tuple[str, float]:
+    """Returns (kind, scale) for the synthetic init of one tensor.
+
+    family 'default': every residual branch carries about as much signal as its shortcut (norm3 gamma 0.5, proj / fc2
+    gain 0.5) -- a chaotic random residual net that amplifies a perturbation ~60x through ResNet stage 2.
+    family 'trained': the conditioning of a trained network -- the last norm of every bottleneck has a small gamma
+    (timm zero-inits it; trained values stay small) and the ViT branch outputs are scaled by 1/sqrt(2*depth) -- so
+    that residual branches are corrections to the stream, as in the published checkpoints."""
     fan_in = 1
     for d in shape[1:]:
         fan_in *= d
@@ -133,7 +142,9 @@ def _gain_for(key: str, shape) -> Tuple[str, float]:
     if ".norm" in key or key.endswith("norm.weight") or key.endswith("norm.bias"):
         # GroupNorm / LayerNorm affine
         if key.endswith(".weight"):
-            return ("gamma", 0.5) if "norm3" in key else ("gamma", 1.0)
+            if "norm3" in key:
+                return ("gamma", 0.2 if family == "trained" else 0.5)
+            return ("gamma", 1.0)
         return "normal", 0.1
     if key.endswith(".bias"):
         if key == "scratch.output_conv.4.bias":
@@ -144,7 +155,7 @@ def _gain_for(key: str, shape) -> Tuple[str, float]:
         return "normal", 0.05  # standardised at run time: scale-free
     g = 1.0
     if "attn.proj" in key or "mlp.fc2" in key:
-        g = 0.5
+        g = (1.0 / (2 * VIT_DEPTH) ** 0.5) if family == "trained" else 0.5
     elif "resConfUnit" in key:
         g = 1.0
     elif "project.0" in key:
@@ -156,13 +167,16 @@ def _gain_for(key: str, shape) -> Tuple[str, float]:
     return "normal", g / (fan_in ** 0.5)
 
 
-def random_state_dict(seed: int = 0, num_channels: int = 3, include_unused: bool = True) -> Dict[str, torch.Tensor]:
-    """Deterministic synthetic fp32 weights (CPU generator => identical on every host)."""
+def random_state_dict(seed: int = 0, num_channels: int = 3, include_unused: bool = True,
+                      family: str = "default") -> Dict[str, torch.Tensor]:
+    """Deterministic synthetic fp32 weights (CPU generator => identical on every host).  `family`: see _gain_for."""
+    if family not in FAMILIES:
+        raise ValueError(f"family must be one of {FAMILIES}")
     g = torch.Generator(device="cpu")
     g.manual_seed(1000003 * int(seed) + 17)
     sd: Dict[str, torch.Tensor] = OrderedDict()
     for key, shape in state_dict_spec(num_channels, include_unused).items():
-        kind, s = _gain_for(key, shape)
+        kind, s = _gain_for(key, shape, family)
         if kind == "const":
             t = torch.full(shape, s, dtype=torch.float32)
         elif kind == "gamma":

@@ -100,17 +100,24 @@ def test_stage_taps_track_oracle(dtype):
     assert not bad, bad
 
 
+GOLDEN_TOL = {**E2E_TOL, "bf16x3": (1e-3, 2e-4)}   # bf16x3 is held to north_star's 1e-3 against the reference's own output
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "bf16x3"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dpt_*.npz"))),
                          ids=lambda p: os.path.basename(p))
-def test_engine_vs_reference_golden(path):
-    """Against vectors produced by the reference's OWN modules (tests/golden/)."""
+def test_engine_vs_reference_golden(path, dtype):
+    """Against vectors produced by the reference's OWN modules (tests/golden/), in the benchmarked dtype (bf16), fp16 and
+    the parity mode (bf16x3, 1e-3)."""
     g = np.load(path)
     task, C, seed, B = str(g["task"]), int(g["num_channels"]), int(g["seed"]), int(g["batch"])
-    y, _, _, _ = run_case(task, C, seed, B, "fp16")
+    y, _, _, _ = run_case(task, C, seed, B, dtype)
+    tol = GOLDEN_TOL[dtype]
     d = np.abs(subsample(y) - g["out_sub"])
-    assert d.max() < E2E_TOL["fp16"][0] and np.sqrt((d ** 2).mean()) < E2E_TOL["fp16"][1]
+    print(f"\n[{os.path.basename(path)} {dtype}] vs reference golden: max|d|={d.max():.3e} rms={np.sqrt((d ** 2).mean()):.3e}")
+    assert d.max() < tol[0] and np.sqrt((d ** 2).mean()) < tol[1]
     row = y.reshape(B, -1, 384, 384)[0, 0, 191].numpy()
-    assert np.abs(row - g["out_row"]).max() < E2E_TOL["fp16"][0]
+    assert np.abs(row - g["out_row"]).max() < tol[0]
 
 
 def test_deterministic_and_batch_invariant():
@@ -148,25 +155,41 @@ def test_input_contract_errors():
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_fused_head_equals_unfused(dtype):
-    """The one-launch head tail (head.hip) against the three-launch path the engine takes while stage taps are on: the
-    only differences are the un-rounded 32-channel map (kept in fp32 registers instead of 16-bit memory) and the fp32
-    summation order of the 1x1 projection."""
+    """The one-launch head tail (head.hip) against the three-launch path the engine takes while stage taps are on.  The
+    two differ only in h1, the 32-channel map in front of the 1x1 projection: fp32 registers in the fused kernel, rounded
+    to 16 bit in memory otherwise (plus fp32 summation order, ~1e-6).  So per output pixel
+        |y_fused - y_unfused| <= sum_c |w4[o,c]| * (half an ulp of h1[c] at that pixel)
+    which is evaluated from the recorded h1 tap -- a bound derived from the data, not a typed-in constant -- and both
+    paths are held to the same budget against the fp32 oracle."""
     sd = random_state_dict(2, 3)
     model = DPTDepthModel(num_channels=3, dtype=dtype, max_batch=2)
     model.load_state_dict(sd)
     model.to(DEV)
-    x = synthetic_input(3, 2, "normal").to(DEV)
-    y_fused = model(x).clone()
+    x = synthetic_input(3, 2, "normal")
+    xg = x.to(DEV)
+    y_fused = model(xg).clone()
     eng = model.engine
     launches_fused = eng.info()[0]  # two half-batch runs on two streams
     eng.enable_taps(True)
-    y_unfused = model(x).clone()      # taps: one run over the whole batch, three launches instead of one for the head tail
+    y_unfused = model(xg).clone()      # taps: one run over the whole batch, three launches instead of one for the head tail
     assert launches_fused == 2 * (eng.info()[0] - 2)
+    h1 = eng.tap("h1").double()        # [B,32,384,384], the 16-bit values the unfused 1x1 projection read
     eng.enable_taps(False)
-    d = (y_fused - y_unfused).abs().max().item()
-    print(f"\n[{dtype}] fused vs unfused head tail: max|d| = {d:.3e}")
-    assert d < (4e-3 if dtype == "bf16" else 5e-4)  # half a 16-bit ulp of h1 (|h1| ~ 1) times sum|w4| ~ 1
-    assert torch.equal(model(x), y_fused)
+    mant = 8 if dtype == "bf16" else 11   # significand bits
+    half_ulp = torch.where(h1 > 0, torch.exp2(torch.floor(torch.log2(h1.clamp_min(1e-30))) - mant), torch.zeros_like(h1))
+    w4 = sd["scratch.output_conv.4.weight"].double().abs().reshape(3, 32)
+    # 1.02: a value within fp32 noise of a rounding boundary may round the other way; 2e-6: fp32 summation order
+    bound = (1.02 * torch.einsum("oc,bchw->bohw", w4, half_ulp) + 2e-6).float()
+    d = (y_fused - y_unfused).abs().cpu()
+    print(f"\n[{dtype}] fused vs unfused head tail: max|d| = {d.max():.3e}, max bound {bound.max():.3e}, "
+          f"worst d/bound {(d / bound).max():.3f}")
+    assert (d <= bound).all()
+    oracle_threads()
+    ref = dpt_forward(sd, x)
+    for name, y in (("fused", y_fused), ("unfused", y_unfused)):
+        e = (y.cpu() - ref).abs()
+        assert e.max() < E2E_TOL[dtype][0] and e.pow(2).mean().sqrt() < E2E_TOL[dtype][1], name
+    assert torch.equal(model(xg), y_fused)
 
 
 def test_two_stream_split_is_bit_identical():
