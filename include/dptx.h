@@ -41,7 +41,22 @@ enum {
  * BF16X3 is the high-precision mode: every 16-bit tensor is a pair of bf16 planes (hi, lo = x - hi,
  * 16 significand bits) and every product is 3 MFMAs (lo*hi + hi*lo + hi*hi) with fp32 accumulate:
  * ~3x the MFMA work and 2x the activation bytes, meets 1e-3 abs against the fp32 reference. */
-enum { DPTX_DTYPE_BF16 = 0, DPTX_DTYPE_FP16 = 1, DPTX_DTYPE_BF16X3 = 2 };
+enum { DPTX_DTYPE_BF16 = 0, DPTX_DTYPE_FP16 = 1, DPTX_DTYPE_BF16X3 = 2,
+       /* FP16X3: the same hi/lo scheme with fp16 planes (hi = fp16(x) is also a valid single-pass fp16 operand).
+        * MIXED : fp16 planes; the layer groups named in dptx_config.x3_groups run with 3 MFMAs per product, the others
+        *         single-pass fp16 on the hi plane -- a per-layer precision policy (profiles/r02_precision_frontier.md). */
+       DPTX_DTYPE_FP16X3 = 3, DPTX_DTYPE_MIXED = 4 };
+/* layer groups of the forward for dptx_config.x3_groups (dtype = DPTX_DTYPE_MIXED).  A 3-MFMA group may only read
+ * tensors produced by 3-MFMA groups (its lo planes must exist): HEAD needs FUSION needs RN needs RESNET and REASSEMBLE;
+ * EMBED needs RESNET; the 12 ViT blocks exchange only the fp32 token stream and are free.  dptx_create rejects others. */
+enum { DPTX_GROUP_RESNET = 1,      /* stem + ResNetV2 stages (convs and GroupNorms)            */
+       DPTX_GROUP_EMBED = 2,       /* patch_embed.proj                                         */
+       DPTX_GROUP_VIT = 4,         /* the 12 transformer blocks (LN, qkv, attention, proj, MLP) */
+       DPTX_GROUP_REASSEMBLE = 8,  /* ProjectReadout + act_postprocess3/4 convs                */
+       DPTX_GROUP_RN = 16,         /* scratch.layerN_rn                                        */
+       DPTX_GROUP_FUSION = 32,     /* scratch.refinenet4..1                                    */
+       DPTX_GROUP_HEAD = 64,       /* scratch.output_conv                                      */
+       DPTX_GROUP_ALL = 127 };
 /* dtype of caller-side image / result buffers */
 enum { DPTX_IO_FP32 = 0 };
 
@@ -58,7 +73,9 @@ typedef struct dptx_config {
   int32_t dual_task;     /* 1: two decoders on one shared encoder (see dptx_forward_dual); needs num_channels = 3 */
   int32_t streams;       /* n = 2..4 (0 = 2): a forward of >= 2 images runs as n sub-batches on n internal streams, */
                          /*   forked from / joined to the caller's stream (same bits, faster); 1: caller's stream only */
-  int32_t reserved[4];   /* must be zero                                                        */
+  int32_t x3_groups;     /* dtype MIXED: OR of DPTX_GROUP_* that run with 3 MFMAs per product; 0 = the default policy  */
+                         /*   (everything except the ViT blocks).  Ignored by the other dtypes.                      */
+  int32_t reserved[3];   /* must be zero                                                        */
 } dptx_config;
 
 /* Fills *cfg with the reference defaults: C=3, max_batch=32, bf16, device 0, non_negative=1,

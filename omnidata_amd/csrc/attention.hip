@@ -232,6 +232,13 @@ hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, 
       done = true;
     }
     hipLaunchKernelGGL((attention_kernel<DT_BF16, 2>), grid, dim3(256), 4 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, pl.act);
+  } else if (mode == MODE_FP16X3) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)attention_kernel<DT_FP16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE);
+      done = true;
+    }
+    hipLaunchKernelGGL((attention_kernel<DT_FP16, 2>), grid, dim3(256), 4 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, pl.act);
   } else
     return hipErrorInvalidValue;
   return hipGetLastError();

@@ -24,12 +24,19 @@ constexpr int DT_FP16 = 1;
 //                    with fp32 accumulation.  The lo plane of a tensor lives at a fixed distance from
 //                    its hi plane: `Planes::act` elements for activations (second half of the arena),
 //                    `Planes::w` for packed GEMM weights (second half of the blob).
-constexpr int MODE_BF16 = 0, MODE_FP16 = 1, MODE_BF16X3 = 2;
+//   3 fp16x3       : the same with fp16 planes: hi = fp16(x) is at the same time the operand of a single-pass fp16
+//                    layer, so one engine can run some layer groups with 3 MFMAs per product and the others with 1
+//                    ("mixed" dtype of the C ABI: dptx_config.x3_groups) without converting tensors in between.
+//                    gfx950's f16 MFMA keeps subnormal inputs (tests/test_gpu_mixed.py pins that), so lo planes that
+//                    fall below 2^-14 still carry their bits (spacing 2^-24).
+constexpr int MODE_BF16 = 0, MODE_FP16 = 1, MODE_BF16X3 = 2, MODE_FP16X3 = 3;
+__host__ __device__ constexpr bool mode_is_x3(int mode) { return mode == MODE_BF16X3 || mode == MODE_FP16X3; }
 #define DPTX_DISPATCH_MODE(mode, ...)                                         \
   switch (mode) {                                                             \
     case ::dptx::MODE_BF16:   { constexpr int DT = ::dptx::DT_BF16, PL = 1; __VA_ARGS__; } break; \
     case ::dptx::MODE_FP16:   { constexpr int DT = ::dptx::DT_FP16, PL = 1; __VA_ARGS__; } break; \
     case ::dptx::MODE_BF16X3: { constexpr int DT = ::dptx::DT_BF16, PL = 2; __VA_ARGS__; } break; \
+    case ::dptx::MODE_FP16X3: { constexpr int DT = ::dptx::DT_FP16, PL = 2; __VA_ARGS__; } break; \
     default: return hipErrorInvalidValue;                                     \
   }
 struct Planes {

@@ -71,6 +71,23 @@ inline uint16_t f32_to_fp16(float f) {
   return (uint16_t)(sign | r);
 }
 
+inline float fp16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, u;
+  if (e == 0) {
+    if (m == 0) u = sign;
+    else {  // subnormal half: normalise
+      int sh = 0;
+      while (!(m & 0x400u)) { m <<= 1; ++sh; }
+      u = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+  else u = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 // --------------------------------------------------------------------------- weight spec
 enum Role { R_STDCONV, R_CONV, R_LINEAR, R_VEC, R_HEAD4, R_UNUSED };
 struct Spec {
@@ -204,6 +221,7 @@ struct TapInfo {
   const void* ptr;
   int64_t shape[4];
   bool fp32;
+  int mode;  // kernel mode of the group that produced it (single-pass groups of a MIXED engine write the hi plane only)
 };
 
 }  // namespace
@@ -227,11 +245,18 @@ struct dptx_engine {
   std::string err;
   std::map<std::string, TapInfo> taps;
   bool taps_on = false;
-  // fused head tail (head.hip): single-plane modes, no stage taps wanted; DPTX_HEAD_FUSED=0 keeps the three launches
+  // kernel mode (common.h MODE_*) of a layer group: the engine dtype, or -- MIXED -- fp16x3 / fp16 per dptx_config.x3_groups
+  int mode_of(int group) const {
+    if (cfg.dtype != DPTX_DTYPE_MIXED) return cfg.dtype;
+    return (cfg.x3_groups & group) ? MODE_FP16X3 : MODE_FP16;
+  }
+  bool two_planes() const { return cfg.dtype == DPTX_DTYPE_BF16X3 || cfg.dtype == DPTX_DTYPE_FP16X3 || cfg.dtype == DPTX_DTYPE_MIXED; }
+  bool bf16_storage() const { return cfg.dtype == DPTX_DTYPE_BF16 || cfg.dtype == DPTX_DTYPE_BF16X3; }
+  // fused head tail (head.hip): single-plane head, no stage taps wanted; DPTX_HEAD_FUSED=0 keeps the three launches
   bool head_fused() const {
     static int env = -1;
     if (env < 0) { const char* t = getenv("DPTX_HEAD_FUSED"); env = (t && t[0] == '0') ? 0 : 1; }
-    return env == 1 && cfg.dtype != DPTX_DTYPE_BF16X3 && !taps_on;
+    return env == 1 && !mode_is_x3(mode_of(DPTX_GROUP_HEAD)) && !taps_on;
   }
   size_t tok_tap_stride = 0;      // floats per token-stream snapshot
   float* d_tok_taps = nullptr;  // [13][max_batch*(max tokens)*768] fp32 copies of the token stream (taps_on)
@@ -331,7 +356,7 @@ void plan_arena(dptx_engine* e) {
   e->half_region = align_up(plan_arena_for(e, (size_t)e->half_batch, true), 256);
   const size_t off = std::max(full, (size_t)ns * e->half_region);
   e->arena_single = off;
-  const int npl = e->cfg.dtype == DPTX_DTYPE_BF16X3 ? 2 : 1;
+  const int npl = e->two_planes() ? 2 : 1;
   e->arena_bytes = off * npl;
   e->pl.act = npl == 2 ? (long long)(off / 2) : 0;
 }
@@ -343,13 +368,18 @@ int pack_host(dptx_engine* e) {
     if (s.role != R_UNUSED && !e->staged.count(s.key)) missing += (missing.empty() ? "" : ", ") + s.key;
   if (!missing.empty()) return e->fail(DPTX_E_KEY, "missing tensors (strict load): " + missing);
   e->host_blob.assign(e->packed_bytes, 0);
-  const bool bf = e->cfg.dtype != DPTX_DTYPE_FP16;
-  const bool x3 = e->cfg.dtype == DPTX_DTYPE_BF16X3;
+  const bool bf = e->bf16_storage();
+  const bool x3 = e->two_planes();
   const size_t lo_elems = e->packed_single / 2;  // uint16 distance hi -> lo plane
   auto bf16_to_f32 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
   // writes element i of a 16-bit tensor (and its lo plane in bf16x3 mode)
   auto put = [&](uint16_t* d16, size_t i, float x) {
-    if (!bf) { d16[i] = f32_to_fp16(x); return; }
+    if (!bf) {
+      const uint16_t hi = f32_to_fp16(x);
+      d16[i] = hi;
+      if (x3) d16[i + lo_elems] = f32_to_fp16(x - fp16_to_f32(hi));
+      return;
+    }
     const uint16_t hi = f32_to_bf16(x);
     d16[i] = hi;
     if (x3) d16[i + lo_elems] = f32_to_bf16(x - bf16_to_f32(hi));
@@ -431,8 +461,9 @@ struct Run {
     }
   }
   void tap(const char* name, const void* p, int64_t h, int64_t w, int64_t c, bool fp32 = false) {
-    e->taps[name] = TapInfo{p, {B, h, w, c}, fp32};
+    e->taps[name] = TapInfo{p, {B, h, w, c}, fp32, dt};
   }
+  void group(int g) { dt = e->mode_of(g); }  // the launches that follow belong to layer group g
 
   // NHWC convolution as implicit GEMM
   void conv(const void* in, int Hin, int Win, int Cin, const std::string& wkey, int ksz, int stride, int pad_t, int pad_l,
@@ -511,6 +542,7 @@ int Run::forward(const float* x, float* y, float* y2) {
   }
 
   // ---- stem: fused conv7x7 s2 SAME (stem.hip, no im2col) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
+  group(DPTX_GROUP_RESNET);
   chk(launch_stem_conv(dt, x, E->w(bp + "stem.conv.weight"), A(E->sraw), B, Hi, Wi, E->pl, st), "stem.conv", 0);
   exec_macs += (double)h2 * w2 * 64 * STEM_K;
   cat_macs[0] += (double)h2 * w2 * 64 * STEM_K;
@@ -558,6 +590,7 @@ int Run::forward(const float* x, float* y, float* y2) {
 
   // ---- tokens: 1x1 proj + bias + pos_embed -> fp32 stream X[b*S + 1 + p] (S = 577 at 384x384); cls rows ----
   float* X = (float*)A(E->X);
+  group(DPTX_GROUP_EMBED);
   {
     GemmParams p;
     gemm_params_dense(p, B * NP, D_VIT, 1024);
@@ -576,7 +609,7 @@ int Run::forward(const float* x, float* y, float* y2) {
     if (!E->taps_on) return;
     float* dst = E->d_tok_taps + (size_t)idx * E->tok_tap_stride;
     if (err == hipSuccess) err = hipMemcpyAsync(dst, X, tok_elems * 4, hipMemcpyDeviceToDevice, st);
-    E->taps[name] = TapInfo{dst, {B, S, D_VIT, 1}, true};
+    E->taps[name] = TapInfo{dst, {B, S, D_VIT, 1}, true, dt};
   };
   tok_tap(0, "tok0");
 
@@ -593,6 +626,7 @@ int Run::forward(const float* x, float* y, float* y2) {
 
   // ProjectReadout + reassemble for hook n (3 -> block 8, 4 -> block 11)
   auto readout = [&](int n) {
+    group(DPTX_GROUP_REASSEMBLE);
     const std::string pp = "pretrained.act_postprocess" + std::to_string(n) + ".";
     float* clsb = (float*)A(E->clsb);
     chk(launch_readout_cls(dt, X, (long long)S * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT, D_VIT,
@@ -626,6 +660,7 @@ int Run::forward(const float* x, float* y, float* y2) {
 
   // ---- 12 transformer blocks (timm Block; LN eps 1e-6) -----------------------------------
   for (int l = 0; l < 12; ++l) {
+    group(DPTX_GROUP_VIT);
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
     chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
     dense(A(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, A(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0);
@@ -655,6 +690,7 @@ int Run::forward(const float* x, float* y, float* y2) {
   const int rn_w[4] = {w4, Wi / 8, gw, w32};
   const int rn_c[4] = {256, 512, 768, 768};
   const char* rn_names[4] = {"l1_rn", "l2_rn", "l3_rn", "l4_rn"};
+  group(DPTX_GROUP_RN);
   for (int i = 0; i < 4; ++i) {
     conv(rn_in[i], rn_h[i], rn_w[i], rn_c[i], pre + "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
          rn_w[i], FEAT, A(E->lrn[i]), nullptr, 0, 0);
@@ -664,6 +700,7 @@ int Run::forward(const float* x, float* y, float* y2) {
   // ---- RefineNet fusion 4 -> 1 (blocks.py:320-341).  out_conv (1x1) is applied BEFORE the x2
   // bilinear upsample: both are linear and the interpolation weights sum to 1, so
   // out_conv(up(x)) == up(out_conv(x)) exactly in real arithmetic, at a quarter of the MACs.
+  group(DPTX_GROUP_FUSION);
   const void* path = nullptr;
   const char* p_names[4] = {"p1", "p2", "p3", "p4"};
   for (int i = 4; i >= 1; --i) {
@@ -684,6 +721,7 @@ int Run::forward(const float* x, float* y, float* y2) {
   }
 
   // ---- head (dpt_depth.py:91-99) ----------------------------------------------------------
+  group(DPTX_GROUP_HEAD);
   const std::string oc = pre + "scratch.output_conv.";
   conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, A(E->H0), E->f(oc + "0.bias"), 0, 0);
   tap((pre + "h0").c_str(), A(E->H0), h2, w2, 128);
@@ -745,12 +783,22 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (cfg->streams < 0 || cfg->streams > 4) return DPTX_E_INVALID;
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
-      (cfg->dtype != DPTX_DTYPE_BF16 && cfg->dtype != DPTX_DTYPE_FP16 && cfg->dtype != DPTX_DTYPE_BF16X3) ||
-      (cfg->ws_form != 0 && cfg->ws_form != 1))
+      cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_MIXED || (cfg->ws_form != 0 && cfg->ws_form != 1))
     return DPTX_E_INVALID;
+  int x3_groups = 0;
+  if (cfg->dtype == DPTX_DTYPE_MIXED) {
+    x3_groups = cfg->x3_groups ? cfg->x3_groups : (DPTX_GROUP_ALL & ~DPTX_GROUP_VIT);
+    if (x3_groups & ~DPTX_GROUP_ALL) return DPTX_E_INVALID;
+    // a 3-MFMA group reads the lo planes of its inputs: every producer of those must be a 3-MFMA group as well
+    auto needs = [&](int g, int producers) { return !(x3_groups & g) || (x3_groups & producers) == producers; };
+    if (!needs(DPTX_GROUP_EMBED, DPTX_GROUP_RESNET) || !needs(DPTX_GROUP_RN, DPTX_GROUP_RESNET | DPTX_GROUP_REASSEMBLE) ||
+        !needs(DPTX_GROUP_FUSION, DPTX_GROUP_RN) || !needs(DPTX_GROUP_HEAD, DPTX_GROUP_FUSION))
+      return DPTX_E_INVALID;
+  }
   dptx_engine* e = new (std::nothrow) dptx_engine();
   if (!e) return DPTX_E_ALLOC;
   e->cfg = *cfg;
+  e->cfg.x3_groups = x3_groups;
   e->max_h = max_h;
   {
     const char* t = getenv("DPTX_STREAMS");  // experiments: overrides cfg.streams
@@ -770,8 +818,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
     }
   }
   e->packed_single = off;
-  e->packed_bytes = off * (cfg->dtype == DPTX_DTYPE_BF16X3 ? 2 : 1);
-  e->pl.w = cfg->dtype == DPTX_DTYPE_BF16X3 ? (long long)(off / 2) : 0;
+  e->packed_bytes = off * (e->two_planes() ? 2 : 1);
+  e->pl.w = e->two_planes() ? (long long)(off / 2) : 0;
   plan_arena(e);
   if (cfg->device_id >= 0) {
     int n = 0;
@@ -986,7 +1034,7 @@ int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_f
   } else {
     float* tmp = nullptr;
     HIPCHK(h, hipMalloc((void**)&tmp, n * 4));
-    hipError_t r = launch_to_f32(h->cfg.dtype, t.ptr, tmp, n, h->pl, nullptr);
+    hipError_t r = launch_to_f32(t.mode, t.ptr, tmp, n, h->pl, nullptr);
     if (r == hipSuccess) r = hipMemcpy(dst_host, tmp, n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     if (r != hipSuccess) return h->fail(DPTX_E_HIP, hipGetErrorString(r));

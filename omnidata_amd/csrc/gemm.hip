@@ -640,6 +640,7 @@ hipError_t launch_gemm(int mode, const GemmParams& p, hipStream_t stream) {
   if (mode == MODE_BF16) return launch_dt<DT_BF16, 1>(p, stream);
   if (mode == MODE_FP16) return launch_dt<DT_FP16, 1>(p, stream);
   if (mode == MODE_BF16X3) return launch_dt<DT_BF16, 2>(p, stream);
+  if (mode == MODE_FP16X3) return launch_dt<DT_FP16, 2>(p, stream);
   return hipErrorInvalidValue;
 }
 

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* _
 
 hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
                             float* y, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream) {
-  if (mode == MODE_BF16X3 || C < 1 || C > 3 || (2 * Hs) % 8 != 0 || (2 * Ws) % 32 != 0) return hipErrorInvalidValue;
+  if (mode_is_x3(mode) || C < 1 || C > 3 || (2 * Hs) % 8 != 0 || (2 * Ws) % 32 != 0) return hipErrorInvalidValue;
   const int ntiles = B * ((2 * Hs) / 8) * ((2 * Ws) / 32);
   static int cus = 0;
   if (cus == 0) {

@@ -12,7 +12,18 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdptx.so")
 
-DTYPES = {"bf16": 0, "fp16": 1, "bf16x3": 2}
+DTYPES = {"bf16": 0, "fp16": 1, "bf16x3": 2, "fp16x3": 3, "mixed": 4}
+# layer groups of dptx_config.x3_groups (include/dptx.h DPTX_GROUP_*)
+GROUPS = {"resnet": 1, "embed": 2, "vit": 4, "reassemble": 8, "rn": 16, "fusion": 32, "head": 64}
+
+
+def groups_mask(names) -> int:
+    """'resnet+embed' / ['resnet', 'embed'] / int -> DPTX_GROUP_* bit mask."""
+    if isinstance(names, int):
+        return names
+    if isinstance(names, str):
+        names = [n for n in names.replace(",", "+").split("+") if n]
+    return sum(GROUPS[n] for n in set(names))
 ERRORS = {0: "ok", -1: "invalid argument / call order", -2: "state_dict key error", -3: "HIP error",
           -4: "no device", -5: "allocation failed"}
 
@@ -21,7 +32,7 @@ class DptxConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32),
                 ("device_id", C.c_int32), ("non_negative", C.c_int32), ("ws_form", C.c_int32),
                 ("ws_eps", C.c_float), ("max_height", C.c_int32), ("max_width", C.c_int32),
-                ("dual_task", C.c_int32), ("streams", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("dual_task", C.c_int32), ("streams", C.c_int32), ("x3_groups", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 # (name, restype, argtypes) for every symbol declared in include/dptx.h
@@ -95,7 +106,7 @@ class Engine:
 
     def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "bf16",
                  device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8,
-                 max_hw: Tuple[int, int] = (384, 384), dual: bool = False, streams: int = 0):
+                 max_hw: Tuple[int, int] = (384, 384), dual: bool = False, streams: int = 0, x3_groups=0):
         self.lib = load_library()
         cfg = DptxConfig()
         self.lib.dptx_default_config(C.byref(cfg))
@@ -105,6 +116,7 @@ class Engine:
         cfg.max_height, cfg.max_width = int(max_hw[0]), int(max_hw[1])
         cfg.dual_task = int(dual)
         cfg.streams = int(streams)
+        cfg.x3_groups = groups_mask(x3_groups)  # dtype "mixed": groups that run 3 MFMAs per product (0 = all but the ViT blocks)
         self.cfg = cfg
         self.dtype = dtype
         self.h = _vp()

@@ -34,14 +34,19 @@ class BaseModel(nn.Module):
 class DPTDepthModel(BaseModel):
     """Drop-in for ``DPTDepthModel(backbone='vitb_rn50_384', num_channels={1,3})``.
 
-    Extra keyword arguments (engine side): ``dtype`` in {'bf16','fp16','bf16x3'} -- MFMA operand /
-    activation storage type ('bf16x3' = hi/lo bf16 planes, 3 MFMAs per product, meets 1e-3 abs); ``max_batch`` -- arena size (larger batches are chunked).
+    Extra keyword arguments (engine side): ``dtype`` in {'bf16','fp16','bf16x3','fp16x3','mixed'} -- MFMA operand /
+    activation storage type.  'bf16' / 'fp16' are single-pass 16-bit arithmetic (fast; they deviate from the fp32
+    reference forward by ~6e-2 / ~7e-3 max-abs on the seeded weights -- NOT within north_star's 1e-3); 'bf16x3' /
+    'fp16x3' keep hi/lo planes and spend 3 MFMAs per product (meet 1e-3); 'mixed' runs the layer groups in
+    ``x3_groups`` ('resnet+reassemble+rn+fusion+head' by default: everything but the ViT blocks) with 3 MFMAs and the
+    rest single-pass fp16 (meets 1e-3 faster; profiles/r02_precision_frontier.md).  ``max_batch`` -- arena size
+    (larger batches are chunked).
     """
 
     def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,
                  backbone: str = "vitb_rn50_384", features: int = 256, readout: str = "project",
                  channels_last: bool = False, use_bn: bool = False, dtype: str = "bf16",
-                 max_batch: int = 32, init_seed: int = 0):
+                 max_batch: int = 32, init_seed: int = 0, x3_groups=0):
         super().__init__()
         if backbone != "vitb_rn50_384":
             # blocks.py:42-44: unknown backbones print and assert
@@ -56,6 +61,7 @@ class DPTDepthModel(BaseModel):
         self.non_negative = bool(non_negative)
         self.channels_last = channels_last  # accepted and, as in the reference (dpt_depth.py:68-69), a no-op
         self.engine_dtype = dtype
+        self.x3_groups = x3_groups
         self.max_batch = max(1, min(int(max_batch), 48))  # engine limit; larger batches are chunked in forward()
         self.max_hw = (384, 384)  # arena is planned for this input size; grows on demand (forward_flex, vit.py:119)
         init = random_state_dict(init_seed, num_channels)
@@ -91,7 +97,8 @@ class DPTDepthModel(BaseModel):
             if self._engine is not None:
                 self._engine.close()
             eng = Engine(num_channels=self.num_channels, max_batch=self._chunk(), dtype=self.engine_dtype,
-                         device_id=key[0], non_negative=self.non_negative, max_hw=self.max_hw)
+                         device_id=key[0], non_negative=self.non_negative, max_hw=self.max_hw,
+                         x3_groups=self.x3_groups)
             eng.load_state_dict(super().state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine
@@ -142,9 +149,11 @@ class DPTDualTaskModel(nn.Module):
     forward(x [B,3,H,W]) -> (normal [B,3,H,W], depth [B,H,W]).
     """
 
-    def __init__(self, dtype: str = "bf16", max_batch: int = 32, init_seed: int = 0, non_negative: bool = True):
+    def __init__(self, dtype: str = "bf16", max_batch: int = 32, init_seed: int = 0, non_negative: bool = True,
+                 x3_groups=0):
         super().__init__()
         self.engine_dtype = dtype
+        self.x3_groups = x3_groups
         self.max_batch = max(1, min(int(max_batch), 48))
         self.max_hw = (384, 384)
         self.non_negative = bool(non_negative)
@@ -192,7 +201,7 @@ class DPTDualTaskModel(nn.Module):
             if self._engine is not None:
                 self._engine.close()
             eng = Engine(num_channels=3, max_batch=self._chunk(), dtype=self.engine_dtype, device_id=key[0],
-                         non_negative=self.non_negative, max_hw=self.max_hw, dual=True)
+                         non_negative=self.non_negative, max_hw=self.max_hw, dual=True, x3_groups=self.x3_groups)
             eng.load_state_dict(super().state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine

@@ -46,12 +46,13 @@ def op_conv(dtype, X, Wt, bias, R, stride, pad_t, pad_l, Ho, Wo, a_relu=0, act=0
 
 
 class PlaneArena:
-    """bf16x3 test storage: every tensor is a (hi, lo) pair of bf16 planes a fixed distance apart,
+    """bf16x3 / fp16x3 test storage: every tensor is a (hi, lo) pair of 16-bit planes a fixed distance apart,
     exactly like the engine's arena/blob halves."""
 
-    def __init__(self, total_elems, device="cuda:0"):
+    def __init__(self, total_elems, device="cuda:0", dtype=torch.bfloat16):
         total_elems = (total_elems + 4095) // 4096 * 4096
-        self.buf = torch.zeros(2, total_elems, dtype=torch.bfloat16, device=device)
+        self.dtype = dtype
+        self.buf = torch.zeros(2, total_elems, dtype=dtype, device=device)
         self.total, self.off = total_elems, 0
         load_library().dptx_op_set_planes(total_elems, total_elems)
 
@@ -64,9 +65,9 @@ class PlaneArena:
     def put(self, t):
         t = t.float().to(self.buf.device)
         o = self._take(t.numel())
-        hi = t.to(torch.bfloat16)
+        hi = t.to(self.dtype)
         self.buf[0, o:o + t.numel()] = hi.flatten()
-        self.buf[1, o:o + t.numel()] = (t - hi.float()).to(torch.bfloat16).flatten()
+        self.buf[1, o:o + t.numel()] = (t - hi.float()).to(self.dtype).flatten()
         return self.buf[0, o:o + t.numel()].view(t.shape)
 
     def empty(self, *shape):
