@@ -228,6 +228,14 @@ int dptx_op_layernorm(int32_t dtype, const float* x, const float* gamma, const f
 int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const float* beta,
                       const void* R, void* Y, int32_t B, int32_t HW, int32_t C, int32_t relu,
                       float eps, void* scratch_f32, void* stream);
+/* Bias-free convolution followed by GroupNorm(32) (+ residual R, + ReLU) the way the ResNetV2 stages run it: the
+ * statistics come out of the conv's GEMM epilogue (fp32 accumulators, one record per 32-row block and group, fixed
+ * order), the apply pass normalises the stored 16-bit map.  Yraw receives the conv output, Y the normalised result
+ * (Y == Yraw allowed).  Ho*Wo % 32 == 0, Cout % 64 == 0; scratch_f32: B * (Ho*Wo/32) * 64 floats. */
+int dptx_op_conv_groupnorm(int32_t dtype, const void* X, const void* Wt, void* Yraw, const float* gamma, const float* beta,
+                           const void* R, void* Y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                           int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo,
+                           int32_t relu, float eps, void* scratch_f32, void* stream);
 /* bilinear x2, align_corners=True, NHWC 16-bit. */
 int dptx_op_upsample2x(int32_t dtype, const void* X, void* Y, int32_t B, int32_t H, int32_t W,
                        int32_t C, void* stream);

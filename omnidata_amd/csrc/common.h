@@ -151,6 +151,21 @@ __device__ __forceinline__ void store8f(uint16_t* p, long long plane, const floa
     *(uint4*)(p + plane) = pack8<DT>(l);
   }
 }
+// 8 x 16-bit in registers (hi plane, lo plane when PL == 2) -> 8 floats
+template <int DT, int PL>
+__device__ __forceinline__ void unpack8x(u32x4_t hi, u32x4_t lo, float* f) {
+  uint4 h;
+  h.x = hi.x; h.y = hi.y; h.z = hi.z; h.w = hi.w;
+  unpack8<DT>(h, f);
+  if (PL == 2) {
+    uint4 l;
+    l.x = lo.x; l.y = lo.y; l.z = lo.z; l.w = lo.w;
+    float g[8];
+    unpack8<DT>(l, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += g[e];
+  }
+}
 // ReLU of a hi/lo pair: sign(x) == sign(hi), so lo is zeroed wherever hi is negative.
 // Whole-vector form (an element-indexed loop over a vector reference was miscompiled by hipcc
 // 7.2 into "element 0 broadcast to all four dwords").

@@ -323,7 +323,8 @@ size_t plan_arena_for(dptx_engine* e, size_t B, bool half) {
   take(e->PA, B * p4 * 256, 2);
   take(e->PB, B * p4 * 256, 2);
   take(e->DS, B * p4 * 256, 2);
-  for (int i = 0; i < 4; ++i) take(e->part[i], B * (p2 / 256 + 64) * 64, 4);
+  // GroupNorm partial records (32 groups x float2): p2/256 chunks for the stem, p4/32 MFMA row blocks for a stage conv
+  for (int i = 0; i < 4; ++i) take(e->part[i], B * (std::max(p2 / 256, p4 / 32) + 64) * 64, 4);
   take(e->X, B * S * D_VIT, 4);
   take(e->Hn, B * S * D_VIT, 2);
   take(e->QKV, B * S * 3 * D_VIT, 2);
@@ -466,9 +467,11 @@ struct Run {
   void group(int g) { dt = e->mode_of(g); }  // the launches that follow belong to layer group g
 
   // NHWC convolution as implicit GEMM
+  // gn_part != nullptr: the epilogue also writes the GroupNorm(32) statistics of the output (per 32-row block records,
+  // kernels.h GemmParams::gn_part); the caller checked gn_fusable(Hout * Wout)
   void conv(const void* in, int Hin, int Win, int Cin, const std::string& wkey, int ksz, int stride, int pad_t, int pad_l,
             int Hout, int Wout, int Cout, void* out, const float* bias, int act, int a_relu, const void* R1 = nullptr,
-            const void* R2 = nullptr) {
+            const void* R2 = nullptr, float* gn_part = nullptr) {
     GemmParams p{};
     p.A = in; p.W = e->w(wkey); p.C = out; p.bias = bias; p.R1 = R1; p.R2 = R2;
     p.M = B * Hout * Wout; p.N = Cout; p.K = ksz * ksz * Cin; p.ldw = p.K;
@@ -479,29 +482,29 @@ struct Run {
     p.c_rpi = 0x7fffffff; p.c_img_rows = 0; p.c_row_off = 0; p.ldc = Cout;
     p.act = act; p.a_relu = a_relu; p.planes = e->pl;
     p.k_tap_fast = (ksz == 3 && Cin >= 512) ? 1 : 0;  // measured per layer: profiles/r01_experiments.md
+    if (gn_part) { p.gn_part = gn_part; p.gn_hw = Hout * Wout; p.gn_blocks = Hout * Wout / 32; p.gn_cpg = Cout / 32; }
     exec_macs += (double)p.M / B * p.N * p.K;
     cat_macs[0] += (double)p.M / B * p.N * p.K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
   }
 
+  // GroupNorm statistics come out of the producing conv's epilogue when an image's rows are whole 32-row MFMA blocks
+  // (always at 384x384; DPTX_GN_FUSED=0 keeps the separate statistics launch for A/B runs)
+  static bool gn_fusable(int HW) {
+    static int env = -1;
+    if (env < 0) { const char* t = getenv("DPTX_GN_FUSED"); env = (t && t[0] == '0') ? 0 : 1; }
+    return env == 1 && HW % 32 == 0;
+  }
   void gn_stats(const void* X, float* part, int HW, int C) { chk(launch_gn_stats(dt, X, part, B, HW, C, e->pl, st), "gn_stats", 2); }
   void gn_apply(void* X, const std::string& nkey, float* part, int HW, int C, int relu, const void* R = nullptr,
                 const std::string& rkey = "", const float* rpart = nullptr) {
     GnParams g{};
+    g.nrec = gn_fusable(HW) ? HW / 32 : 0;
     g.X = X; g.Y = X; g.gamma = e->f(nkey + ".weight"); g.beta = e->f(nkey + ".bias"); g.partial = part;
     g.R = R;
     if (!rkey.empty()) { g.r_gamma = e->f(rkey + ".weight"); g.r_beta = e->f(rkey + ".bias"); g.r_partial = rpart; }
     g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = 1e-5f;
     chk(launch_gn_apply(dt, g, e->pl, st), nkey.c_str(), 2);
-  }
-
-  // GroupNorm (+ plain residual, + ReLU) in place: statistics launch + apply launch.  (A single-launch variant that held
-  // a 64-channel slab of a small map in registers was measured at +0.7 % end to end and removed: reading the output of
-  // the preceding GEMM it returned stale values in ~1 % of launches whenever a second stream kept the GPU busy --
-  // profiles/r01_experiments.md.)
-  void gn(void* X, const std::string& nkey, float* part, int HW, int C, int relu, const void* R = nullptr) {
-    gn_stats(X, part, HW, C);
-    gn_apply(X, nkey, part, HW, C, relu, R);
   }
 
   // RCU (blocks.py:263-286): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
@@ -562,23 +565,28 @@ int Run::forward(const float* x, float* y, float* y2) {
       const int stride = (b == 0) ? STAGE_STRIDE[s] : 1;
       const int Ho = H / stride, Wo = Wd / stride;
       void* out = (b == STAGE_DEPTH[s] - 1) ? (void*)A(E->S[s]) : (void*)((b & 1) ? A(E->PB) : A(E->PA));
+      const bool f_in = gn_fusable(H * Wd), f_out = gn_fusable(Ho * Wo);  // statistics from the conv epilogues
       if (b == 0) {
-        conv(cur, H, Wd, cin, p + "downsample.conv.weight", 1, stride, 0, 0, Ho, Wo, cout, A(E->DS), nullptr, 0, 0);
-        gn_stats(A(E->DS), part3, Ho * Wo, cout);
+        conv(cur, H, Wd, cin, p + "downsample.conv.weight", 1, stride, 0, 0, Ho, Wo, cout, A(E->DS), nullptr, 0, 0, nullptr, nullptr,
+             f_out ? part3 : nullptr);
+        if (!f_out) gn_stats(A(E->DS), part3, Ho * Wo, cout);
       }
-      conv(cur, H, Wd, cin, p + "conv1.weight", 1, 1, 0, 0, H, Wd, mid, A(E->T1), nullptr, 0, 0);
-      gn(A(E->T1), p + "norm1", part0, H * Wd, mid, 1);
+      conv(cur, H, Wd, cin, p + "conv1.weight", 1, 1, 0, 0, H, Wd, mid, A(E->T1), nullptr, 0, 0, nullptr, nullptr, f_in ? part0 : nullptr);
+      if (!f_in) gn_stats(A(E->T1), part0, H * Wd, mid);
+      gn_apply(A(E->T1), p + "norm1", part0, H * Wd, mid, 1);
       // 3x3, stride on conv2 (V1.5); TF-SAME: s1 -> pad (1,1); s2 on even H -> pad (0,1)
       const int pad = (stride == 1) ? 1 : 0;
-      conv(A(E->T1), H, Wd, mid, p + "conv2.weight", 3, stride, pad, pad, Ho, Wo, mid, A(E->T2), nullptr, 0, 0);
-      gn(A(E->T2), p + "norm2", part1, Ho * Wo, mid, 1);
-      conv(A(E->T2), Ho, Wo, mid, p + "conv3.weight", 1, 1, 0, 0, Ho, Wo, cout, out, nullptr, 0, 0);
-      if (b == 0) {
-        gn_stats(out, part2, Ho * Wo, cout);
+      conv(A(E->T1), H, Wd, mid, p + "conv2.weight", 3, stride, pad, pad, Ho, Wo, mid, A(E->T2), nullptr, 0, 0, nullptr, nullptr,
+           f_out ? part1 : nullptr);
+      if (!f_out) gn_stats(A(E->T2), part1, Ho * Wo, mid);
+      gn_apply(A(E->T2), p + "norm2", part1, Ho * Wo, mid, 1);
+      conv(A(E->T2), Ho, Wo, mid, p + "conv3.weight", 1, 1, 0, 0, Ho, Wo, cout, out, nullptr, 0, 0, nullptr, nullptr,
+           f_out ? part2 : nullptr);
+      if (!f_out) gn_stats(out, part2, Ho * Wo, cout);
+      if (b == 0)
         gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, A(E->DS), p + "downsample.norm", part3);
-      } else {
-        gn(out, p + "norm3", part2, Ho * Wo, cout, 1, cur);
-      }
+      else
+        gn_apply(out, p + "norm3", part2, Ho * Wo, cout, 1, cur);
       cur = out;
       H = Ho;
       Wd = Wo;
@@ -1154,6 +1162,28 @@ int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const fl
   GnParams g{};
   g.X = X; g.Y = Y; g.gamma = gamma; g.beta = beta; g.partial = (float*)scratch_f32; g.R = R;
   g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = eps;
+  return launch_gn_apply(dtype, g, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_conv_groupnorm(int32_t dtype, const void* X, const void* Wt, void* Yraw, const float* gamma, const float* beta,
+                           const void* R, void* Y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                           int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, int32_t relu, float eps,
+                           void* scratch_f32, void* stream) {
+  if (scratch_f32 == nullptr || (Ho * Wo) % 32 != 0) return DPTX_E_INVALID;
+  GemmParams p{};
+  p.A = X; p.W = Wt; p.C = Yraw;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = ksize * ksize * Cin; p.ldw = p.K;
+  p.a_rpi = Ho * Wo; p.Wout = Wo; p.Hin = H; p.Win = W; p.Cin = Cin; p.a_pix_stride = Cin;
+  p.a_img_stride = (long long)H * W * Cin;
+  p.a_bytes = (long long)B * H * W * Cin * 2;
+  p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.c_rpi = 0x7fffffff; p.ldc = Cout; p.planes = g_op_planes;
+  p.k_tap_fast = (ksize == 3 && Cin >= 512) ? 1 : 0;
+  p.gn_part = (float*)scratch_f32; p.gn_hw = Ho * Wo; p.gn_blocks = Ho * Wo / 32; p.gn_cpg = Cout / 32;
+  if (launch_gemm(dtype, p, (hipStream_t)stream) != hipSuccess) return DPTX_E_HIP;
+  GnParams g{};
+  g.X = Yraw; g.Y = Y; g.gamma = gamma; g.beta = beta; g.partial = (float*)scratch_f32; g.R = R;
+  g.B = B; g.HW = Ho * Wo; g.C = Cout; g.relu = relu; g.eps = eps; g.nrec = Ho * Wo / 32;
   return launch_gn_apply(dtype, g, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 

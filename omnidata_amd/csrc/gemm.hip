@@ -24,6 +24,7 @@
 // * 1-D grid, XCD-aware bijective remap; n-tile fastest so the blocks of one XCD re-use the
 //   same A rows out of that XCD's L2.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -31,6 +32,22 @@
 namespace dptx {
 
 constexpr int BK = 64;
+
+// q = m / d, rem = m % d for 0 <= m < 2^23 without the ~35-instruction integer division: float(m) is exact, the product
+// with the rounded reciprocal is off by < 1, one correction step either way.  `big` (uniform): exact division.
+__device__ __forceinline__ int row_div(int m, int d, float rcp, bool big, int& rem) {
+  if (big) {
+    const int q = m / d;
+    rem = m - q * d;
+    return q;
+  }
+  int q = (int)((float)m * rcp);
+  int r = m - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+  rem = r;
+  return q;
+}
 
 // ----------------------------------------------------------------------------- shared pieces
 template <int DT, int TM, int TN, bool RELU_A, int PL = 1, int HK = BK / 16>
@@ -114,35 +131,56 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
 // SLABS == 1: the whole BM x BN tile goes through LDS at once.  SLABS == TM (256x256 block: the fp32 tile would be
 // 266 KB): TM passes, pass s carries the s-th 32-row MFMA tile of every wave -- LDS row q = (wave row)*32 + r is tile
 // row (q/32)*(TM*32) + s*32 + q%32.
+//
+// Memory-level parallelism: a thread owns ITER rows x 8 columns of a slab.  All of its residual / per-image-bias loads
+// are issued BEFORE the accumulators are staged through LDS, so their latency (1-2 us next to a second busy block) is
+// paid once per slab under the staging, not once per row; with C == R1 (the in-place residual stream) every thread
+// reads exactly the elements it later writes, so the order loads -> stores is also what makes that legal.
+//
+// GroupNorm statistics (p.gn_part): per 32-row MFMA block and group, (sum, sum of squares) of the fp32 accumulators,
+// reduced in a fixed order (16 registers, lane^32, then lane^1..cpg/2) and written -- not accumulated -- to
+// partial[img][block][group]: no atomics, and the value of a record depends on the image's own rows only, so the
+// statistics are bit-identical run to run and at every batch size (needs rows-per-image % 32 == 0; the engine falls
+// back to the gn_stats kernel otherwise).
 template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                          int tid, f32x16_t (&acc)[TM][TN]) {
   static_assert(SLABS == 1 || SLABS == TM, "one slab, or one per MFMA row tile");
   constexpr int CT_PITCH = BN + 4;  // floats
   constexpr int CT_ROWS = BM / SLABS;
-  float* ct = (float*)smem;
-#pragma unroll
- for (int s = 0; s < SLABS; ++s) {
-  if (s > 0) __syncthreads();  // the previous slab has been read out
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    if (SLABS != 1 && i != s) continue;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = (SLABS == 1 ? wm * (TM * 32) + i * 32 : wm * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int nl = wn * (TN * 32) + j * 32 + lr;
-        ct[ml * CT_PITCH + nl] = acc[i][j][r];
-      }
-  }
-  __syncthreads();
-
   constexpr int NCH = BN / 8;     // 8-column chunks per tile row
   constexpr int RPP = NT / NCH;   // tile rows per pass
+  constexpr int ITER = CT_ROWS / RPP;
+  static_assert(CT_ROWS % RPP == 0, "rows per pass must divide the slab");
+  float* ct = (float*)smem;
   const int cn = tid % NCH;
   const int rr = tid / NCH;
   const int n = n0 + cn * 8;
+
+  if (p.gn_part != nullptr) {
+    const int cpg = p.gn_cpg;  // channels per group: 2..32, a power of two
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + (wm * TM + i) * 32;  // first GEMM row of this wave's i-th 32-row block
+      const int img = mb / p.gn_hw;
+      const int blk = (mb - img * p.gn_hw) >> 5;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sm += v; sq = fmaf(v, v, sq); }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        for (int o = 1; o < cpg; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
+        if (lh == 0 && (lr & (cpg - 1)) == 0 && mb < p.M) {
+          const int g = (n0 + (wn * TN + j) * 32 + lr) / cpg;
+          float2* dst = (float2*)p.gn_part + ((long long)img * p.gn_blocks + blk) * 32 + g;
+          *dst = make_float2(sm, sq);
+        }
+      }
+    }
+  }
+
   float bias_c[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias_c[e] = 0.f;
@@ -151,78 +189,162 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
     bias_c[0] = b0.x; bias_c[1] = b0.y; bias_c[2] = b0.z; bias_c[3] = b0.w;
     bias_c[4] = b1.x; bias_c[5] = b1.y; bias_c[6] = b1.z; bias_c[7] = b1.w;
   }
-#pragma unroll 2
-  for (int row = rr; row < CT_ROWS; row += RPP) {
-    const int m = m0 + (SLABS == 1 ? row : (row >> 5) * (TM * 32) + s * 32 + (row & 31));
-    if (m >= p.M) break;
-    // token-row remap (patch-embed, readout): image / row-in-image of GEMM row m; everything else has c_rpi = INT_MAX
-    // and skips the integer division (a uniform branch; ~30 VALU instructions per row otherwise)
-    int img = 0, pp = m;
-    if (p.c_rpi != 0x7fffffff) {
-      img = m / p.c_rpi;
-      pp = m - img * p.c_rpi;
-    }
-    const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
-    float v[8];
-    {
-      const float4 x0 = *(const float4*)(ct + row * CT_PITCH + cn * 8);
-      const float4 x1 = *(const float4*)(ct + row * CT_PITCH + cn * 8 + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
-      v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-    }
-    if (p.bias_per_img) {
-      const float* bp = p.bias + (long long)img * p.N + n;
-      const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-      v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    } else {
+  const bool remap = p.c_rpi != 0x7fffffff;  // token-row remap (patch-embed, readout); everything else skips the division
+  // rows per load group: 4 (96 registers of loads in flight at most); 2 for the slab epilogue, whose 128 accumulator
+  // registers stay live across the slabs
+  constexpr int GR = SLABS > 1 ? 2 : (ITER < 4 ? ITER : 4);
+  constexpr int NGR = ITER / GR;
+  static_assert(ITER % GR == 0, "row groups");
+
+  // The body is instantiated per residual configuration (R1M / R2M: 0 none, 1 16-bit, 2 fp32, -1 decided at run time;
+  // BPI: per-image bias 0 / 1 / -1) and selected by ONE uniform branch below: inside an instance the loads are
+  // unconditional, so the compiler keeps them where they are written -- all up front -- instead of sinking each one
+  // into the conditional block that consumes it (which serialises a memory latency per row).
+  auto body = [&](auto r1m_, auto r2m_, auto bpi_) {
+    constexpr int R1M = decltype(r1m_)::value, R2M = decltype(r2m_)::value, BPI = decltype(bpi_)::value;
+    const bool r1 = R1M < 0 ? p.R1 != nullptr : R1M > 0, r2 = R2M < 0 ? p.R2 != nullptr : R2M > 0;
+    const bool r1f = R1M < 0 ? p.r1_fp32 != 0 : R1M == 2, r2f = R2M < 0 ? p.r2_fp32 != 0 : R2M == 2;
+    const bool bpi = BPI < 0 ? p.bias_per_img != 0 : BPI > 0;
+    long long coff[GR];
+    bool ok[GR];
+    u32x4_t ra[GR][2], rb[GR][2], bb[GR][2];
+    // addresses and every global load of row group `gi` of slab `s`
+    auto issue_loads = [&](int s, int gi) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bias_c[e];
-    }
-    if (p.act == 1) {
+      for (int it = 0; it < GR; ++it) {
+        const int row = rr + (gi * GR + it) * RPP;
+        int m = m0 + (SLABS == 1 ? row : (row >> 5) * (TM * 32) + s * 32 + (row & 31));
+        ok[it] = m < p.M;
+        m = ok[it] ? m : m0;  // any valid row: the loads stay in bounds, the store is masked
+        int img = 0, pp = m;
+        if (remap) {
+          img = m / p.c_rpi;
+          pp = m - img * p.c_rpi;
+        }
+        const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
+        coff[it] = crow * p.ldc + n;
+        if (r1) {
+          if (r1f) {
+            const u32x4_t* src = (const u32x4_t*)((const float*)p.R1 + coff[it]);
+            ra[it][0] = src[0];
+            ra[it][1] = src[1];
+          } else {
+            ra[it][0] = *(const u32x4_t*)((const uint16_t*)p.R1 + coff[it]);
+            if (PL == 2) ra[it][1] = *(const u32x4_t*)((const uint16_t*)p.R1 + p.planes.act + coff[it]);
+          }
+        }
+        if (r2) {
+          const long long off = p.r2_bcast ? (long long)(p.c_row_off + pp) * p.ldc + n : coff[it];
+          if (r2f) {
+            const u32x4_t* src = (const u32x4_t*)((const float*)p.R2 + off);
+            rb[it][0] = src[0];
+            rb[it][1] = src[1];
+          } else {
+            rb[it][0] = *(const u32x4_t*)((const uint16_t*)p.R2 + off);
+            if (PL == 2) rb[it][1] = *(const u32x4_t*)((const uint16_t*)p.R2 + p.planes.act + off);
+          }
+        }
+        if (bpi) {
+          const u32x4_t* src = (const u32x4_t*)(p.bias + (long long)img * p.N + n);
+          bb[it][0] = src[0];
+          bb[it][1] = src[1];
+        }
+      }
+    };
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-    } else if (p.act == 2) {
+    for (int s = 0; s < SLABS; ++s) {
+      // ---- (a) the first row group's loads fly while the accumulators are staged
+      issue_loads(s, 0);
+      // ---- (b) accumulators -> LDS
+      if (s > 0) __syncthreads();  // the previous slab has been read out
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-    }
-    if (p.R1 != nullptr) {
-      const long long off = crow * p.ldc + n;
-      if (p.r1_fp32) {
-        const float4 a0 = *(const float4*)((const float*)p.R1 + off), a1 = *(const float4*)((const float*)p.R1 + off + 4);
-        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
-        v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
-      } else {
-        float f[8];
-        load8f<DT, PL>((const uint16_t*)p.R1 + off, p.planes.act, f);
+      for (int i = 0; i < TM; ++i) {
+        if (SLABS != 1 && i != s) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += f[e];
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ml = (SLABS == 1 ? wm * (TM * 32) + i * 32 : wm * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int nl = wn * (TN * 32) + j * 32 + lr;
+            ct[ml * CT_PITCH + nl] = acc[i][j][r];
+          }
+      }
+      __syncthreads();
+      // ---- (c) rows out
+#pragma unroll
+      for (int gi = 0; gi < NGR; ++gi) {
+        if (gi > 0) issue_loads(s, gi);
+#pragma unroll
+        for (int it = 0; it < GR; ++it) {
+          const int row = rr + (gi * GR + it) * RPP;
+          float v[8];
+          {
+            const float4 x0 = *(const float4*)(ct + row * CT_PITCH + cn * 8);
+            const float4 x1 = *(const float4*)(ct + row * CT_PITCH + cn * 8 + 4);
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+            v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+          }
+          if (bpi) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(bb[it][0][e]); v[4 + e] += __uint_as_float(bb[it][1][e]); }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias_c[e];
+          }
+          if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+          }
+          if (r1) {
+            if (r1f) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(ra[it][0][e]); v[4 + e] += __uint_as_float(ra[it][1][e]); }
+            } else {
+              float f[8];
+              unpack8x<DT, PL>(ra[it][0], ra[it][1], f);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += f[e];
+            }
+          }
+          if (r2) {
+            if (r2f) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(rb[it][0][e]); v[4 + e] += __uint_as_float(rb[it][1][e]); }
+            } else {
+              float f[8];
+              unpack8x<DT, PL>(rb[it][0], rb[it][1], f);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += f[e];
+            }
+          }
+          if (ok[it]) {
+            if (p.c_fp32) {
+              float* cp = (float*)p.C + coff[it];
+              *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+              *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+              store8f<DT, PL>((uint16_t*)p.C + coff[it], p.planes.act, v);
+            }
+          }
+        }
       }
     }
-    if (p.R2 != nullptr) {
-      const long long r2row = p.r2_bcast ? (long long)(p.c_row_off + pp) : crow;
-      const long long off = r2row * p.ldc + n;
-      if (p.r2_fp32) {
-        const float4 a0 = *(const float4*)((const float*)p.R2 + off), a1 = *(const float4*)((const float*)p.R2 + off + 4);
-        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
-        v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
-      } else {
-        float f[8];
-        load8f<DT, PL>((const uint16_t*)p.R2 + off, p.planes.act, f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += f[e];
-      }
-    }
-    const long long coff = crow * p.ldc + n;
-    if (p.c_fp32) {
-      float* cp = (float*)p.C + coff;
-      *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
-      *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
-      store8f<DT, PL>((uint16_t*)p.C + coff, p.planes.act, v);
-    }
-  }
- }
+  };
+  using std::integral_constant;
+  const bool has1 = p.R1 != nullptr, has2 = p.R2 != nullptr;
+  if (!has1 && !has2 && !p.bias_per_img)
+    body(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // qkv, fc1, most convs
+  else if (has1 && p.r1_fp32 && !has2 && !p.bias_per_img)
+    body(integral_constant<int, 2>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // proj, fc2: fp32 stream
+  else if (has1 && !p.r1_fp32 && !has2 && !p.bias_per_img)
+    body(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // RCU conv2
+  else if (has1 && !p.r1_fp32 && has2 && !p.r2_fp32 && !p.bias_per_img)
+    body(integral_constant<int, 1>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{});  // RCU conv2 + path
+  else
+    body(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});  // patch-embed, readout
 }
 
 // ------------------------------------------------------------------- direct-to-LDS kernel
@@ -276,10 +398,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
     const int m = m0 + r0 + ROWS_PP * i;
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
-    const int img = mm / p.a_rpi;
-    const int rem = mm - img * p.a_rpi;
-    const int oy = rem / p.Wout;
-    const int ox = rem - oy * p.Wout;
+    int rem, ox;  // M < 2^23 on this path (launch_cfg): reciprocal division
+    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
+    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
     a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;  // rows >= M never pass the bounds test
     a_ix0[i] = ox * p.stride - p.pad_l;
     const long long e = (long long)img * p.a_img_stride + p.a_off +
@@ -394,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
   }
 
   const int kc = tid & 7, r0 = tid >> 3;
+  const bool big_m = p.M >= (1 << 23);
   int a_iy0[A_PASSES], a_ix0[A_PASSES];
   long long a_base[A_PASSES];
 #pragma unroll
@@ -401,10 +523,9 @@ __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
     const int m = m0 + r0 + 32 * i;
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
-    const int img = mm / p.a_rpi;
-    const int rem = mm - img * p.a_rpi;
-    const int oy = rem / p.Wout;
-    const int ox = rem - oy * p.Wout;
+    int rem, ox;
+    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, big_m, rem);
+    const int oy = row_div(rem, p.Wout, p.wout_rcp, big_m, ox);
     a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
     a_ix0[i] = ox * p.stride - p.pad_l;
     a_base[i] = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + kc * 8;
@@ -560,7 +681,8 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   choose_xcd_grid(p, tiles_m, tiles_n, q.xcd_m, q.xcd_n);
   const int tiles = 8 * ((tiles_m + q.xcd_m - 1) / q.xcd_m) * (tiles_n / q.xcd_n);
   constexpr size_t smem = gemm_smem_bytes<BM, BN, PL>();
-  const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31);
+  const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
+                       p.M < (1 << 23);
   if (PL == 2 && !glds_ok) return hipErrorInvalidValue;  // the 3-pass mode exists only on the direct-to-LDS path
   if (glds_ok && (PL == 2 || gemm_variant() != 1)) {
     if (p.a_relu) {
@@ -609,7 +731,7 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // on long-K problems whose tile count fills the 256 CUs evenly (fc2, the 3x3 convs at 1/4 resolution), -2..-22 %
   // elsewhere -- so: K >= 2048 and >= 85 % of the last round of CUs busy.
   if constexpr (PL == 1) {
-    const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && gemm_variant() != 1;
+    const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
     static int min_k = -1;  // DPTX_T256_MINK: shortest K that takes the 256x256 tile (experiments)
     if (min_k < 0) { const char* t = getenv("DPTX_T256_MINK"); min_k = t ? atoi(t) : 2048; }
     const long long t256 = m256 * (p.N / 256), rounds = (t256 + 255) / 256;
@@ -635,7 +757,13 @@ void gemm_params_dense(GemmParams& p, int M, int N, int K) {
   p.a_bytes = (long long)M * K * 2;
 }
 
-hipError_t launch_gemm(int mode, const GemmParams& p, hipStream_t stream) {
+hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
+  GemmParams p = p0;
+  p.a_rpi_rcp = 1.0f / (float)(p.a_rpi > 0 ? p.a_rpi : 1);
+  p.wout_rcp = 1.0f / (float)(p.Wout > 0 ? p.Wout : 1);
+  if (p.gn_part != nullptr && (p.gn_hw % 32 != 0 || p.N % 32 != 0 || p.gn_cpg != p.N / 32 || p.gn_cpg < 2 || p.gn_cpg > 32 ||
+                               (p.gn_cpg & (p.gn_cpg - 1)) != 0 || p.bias != nullptr || p.act != 0))
+    return hipErrorInvalidValue;  // statistics are those of the raw accumulators: no bias / activation in front of a GroupNorm
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 8 != 0) return hipErrorInvalidValue;
   if (mode == MODE_BF16) return launch_dt<DT_BF16, 1>(p, stream);
   if (mode == MODE_FP16) return launch_dt<DT_FP16, 1>(p, stream);

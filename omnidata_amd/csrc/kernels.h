@@ -37,6 +37,11 @@ struct GemmParams {
   Planes planes;  // hi->lo plane distances (bf16x3 mode only)
   int xcd_m, xcd_n;  // XCD grid of the tile partition (filled in by launch_gemm)
   int k_tap_fast;    // visit the k-tiles taps-fastest inside a 64-channel block (3x3 convs with Cin >= 512: +12..17 %)
+  // GroupNorm(32) statistics of the output from the epilogue (null: none): partial[img][gn_blocks][32] float2 records
+  // of (sum, sum of squares) per 32-row block; gn_hw = rows per image (% 32 == 0), gn_cpg = N / 32 channels per group
+  float* gn_part;
+  int gn_hw, gn_blocks, gn_cpg;
+  float a_rpi_rcp, wout_rcp;  // 1 / a_rpi, 1 / Wout (filled in by launch_gemm: row -> (image, y, x) without integer division)
 };
 
 // Fills the "plain dense row-major" defaults for A [M,K] (lda = K) and C [M,N].
@@ -59,6 +64,8 @@ struct GnParams {
   const float* r_gamma; const float* r_beta; const float* r_partial;  // optional GN on residual
   int B, HW, C, relu;
   float eps;
+  int nrec;  // partial records per image in `partial` / `r_partial`: 0 = gn_chunks(HW, C) (written by launch_gn_stats),
+             // HW / 32 when a GEMM epilogue wrote them (GemmParams::gn_part)
 };
 int gn_chunks(int HW, int C);  // blocks per image of the GroupNorm stats/apply grids = partial records per image
 hipError_t launch_gn_stats(int mode, const void* X, float* partial, int B, int HW, int C, Planes pl, hipStream_t stream);

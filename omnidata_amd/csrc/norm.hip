@@ -182,12 +182,12 @@ __device__ __forceinline__ void gn_affine_to_lds(const float* __restrict__ parti
 }
 
 template <int DT, int PL>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix, int nchunks, long long plane) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix, int nrec, long long plane) {
   __shared__ float sa[1024], sd[1024], ra[1024], rd[1024], smr[64];
   const int b = blockIdx.y;
-  gn_affine_to_lds(p.partial, nchunks, b, p.gamma, p.beta, p.C, p.HW, p.eps, sa, sd, smr);
+  gn_affine_to_lds(p.partial, nrec, b, p.gamma, p.beta, p.C, p.HW, p.eps, sa, sd, smr);
   const bool r_gn = (p.R != nullptr) && (p.r_gamma != nullptr);
-  if (r_gn) gn_affine_to_lds(p.r_partial, nchunks, b, p.r_gamma, p.r_beta, p.C, p.HW, p.eps, ra, rd, smr);
+  if (r_gn) gn_affine_to_lds(p.r_partial, nrec, b, p.r_gamma, p.r_beta, p.C, p.HW, p.eps, ra, rd, smr);
   const int cvec = p.C >> 3;
   const int pbeg = blockIdx.x * pix;
   const int pend = min(pbeg + pix, p.HW);
@@ -225,7 +225,8 @@ hipError_t launch_gn_apply(int mode, const GnParams& p, Planes pl, hipStream_t s
   if (p.C % 64 != 0 || p.C > 1024) return hipErrorInvalidValue;
   const int nch = gn_chunks(p.HW, p.C);
   dim3 grid(nch, p.B);
-  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_apply_kernel<DT, PL>), grid, dim3(256), 0, stream, p, gn_pix(p.C), nch, pl.act));
+  const int nrec = p.nrec > 0 ? p.nrec : nch;
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_apply_kernel<DT, PL>), grid, dim3(256), 0, stream, p, gn_pix(p.C), nrec, pl.act));
   return hipGetLastError();
 }
 

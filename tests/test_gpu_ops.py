@@ -146,6 +146,48 @@ def test_groupnorm(dtype, B, HW, C, relu, res):
     assert rel_err(Y.float(), ref) < OUT_TOL[dtype]
 
 
+# (B, H, Cin, Cout, k, stride, pad, Ho, residual): every tile shape the ResNetV2 stage convs take, incl. a ragged last
+# m-tile (B*Ho*Ho not a multiple of the tile), images that end inside a tile (576 rows), cpg from 2 to 32
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 96, 64, 64, 1, 1, 0, 96, False), (3, 24, 256, 1024, 1, 1, 0, 24, True),
+                                  (3, 24, 256, 256, 3, 1, 1, 24, False), (2, 48, 128, 512, 1, 1, 0, 48, True),
+                                  (1, 96, 128, 128, 3, 2, 0, 48, False), (5, 24, 1024, 256, 1, 1, 0, 24, False),
+                                  (32, 24, 512, 256, 1, 1, 0, 24, False)])
+def test_conv_groupnorm_fused_stats(dtype, case):
+    """GroupNorm statistics out of the conv's GEMM epilogue (what the ResNetV2 stages run) against conv -> group_norm."""
+    lib = load_library()
+    B, H, Cin, Cout, k, stride, pad, Ho, res = case
+    X = rnd(B, H, H, Cin, dtype=dtype, seed=20)
+    Wt = rnd(Cout, k, k, Cin, dtype=dtype, scale=(k * k * Cin) ** -0.5, seed=21)
+    g, b = torch.randn(Cout, device=DEV), torch.randn(Cout, device=DEV)
+    R = rnd(B, Ho, Ho, Cout, dtype=dtype, seed=22) if res else None
+    Yraw = torch.empty(B, Ho, Ho, Cout, device=DEV, dtype=TDT[dtype])
+    Y = torch.empty_like(Yraw)
+    scratch = torch.zeros(B * (Ho * Ho // 32) * 64, device=DEV)
+    rc = lib.dptx_op_conv_groupnorm(DTYPES[dtype], ptr(X), ptr(Wt), ptr(Yraw), ptr(g), ptr(b), ptr(R), ptr(Y), B, H, H, Cin,
+                                    Cout, k, stride, pad, pad, Ho, Ho, 1, 1e-5, ptr(scratch), stream())
+    assert rc == 0
+    raw = conv_ref(X, Wt, None, stride, pad, pad, Ho, Ho, 0)          # fp32 conv of the 16-bit operands, NHWC
+    assert rel_err(Yraw.float(), raw) < OUT_TOL[dtype]
+    # the statistics are those of the fp32 accumulators; the apply pass normalises the stored (rounded) map
+    xr = raw.permute(0, 3, 1, 2).reshape(B, 32, -1)
+    mean, var = xr.mean(-1), xr.var(-1, unbiased=False)
+    a = (g.view(1, -1) * torch.rsqrt(var + 1e-5).repeat_interleave(Cout // 32, 1))
+    ref = Yraw.float() * a.view(B, 1, 1, Cout) + (b.view(1, -1) - mean.repeat_interleave(Cout // 32, 1) * a).view(B, 1, 1, Cout)
+    if res:
+        ref = ref + R.float()
+    ref = F.relu(ref)
+    assert rel_err(Y.float(), ref) < OUT_TOL[dtype]
+    # batch invariance, bit for bit: image i of the batch == image i alone
+    i = B - 1
+    Y1 = torch.empty(1, Ho, Ho, Cout, device=DEV, dtype=TDT[dtype])
+    R1 = R[i:i + 1].contiguous() if res else None
+    rc = lib.dptx_op_conv_groupnorm(DTYPES[dtype], ptr(X[i:i + 1].contiguous()), ptr(Wt), ptr(Y1), ptr(g), ptr(b), ptr(R1), ptr(Y1),
+                                    1, H, H, Cin, Cout, k, stride, pad, pad, Ho, Ho, 1, 1e-5, ptr(scratch), stream())
+    assert rc == 0
+    assert torch.equal(Y1[0], Y[i])
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,H,C", [(2, 12, 256), (1, 96, 256), (2, 48, 128)])
 def test_upsample2x_align_corners(dtype, B, H, C):
