@@ -224,9 +224,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p, int pix
 hipError_t launch_gn_apply(int mode, const GnParams& p, Planes pl, hipStream_t stream) {
   if (p.C % 64 != 0 || p.C > 1024) return hipErrorInvalidValue;
   const int nch = gn_chunks(p.HW, p.C);
-  dim3 grid(nch, p.B);
   const int nrec = p.nrec > 0 ? p.nrec : nch;
-  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_apply_kernel<DT, PL>), grid, dim3(256), 0, stream, p, gn_pix(p.C), nrec, pl.act));
+  // every block re-reduces its image's partial records in its prologue (nrec x 256 B from L2): with the fine records of
+  // the GEMM epilogue (one per 32 rows) that costs more than the block's own share of the map unless blocks are fat --
+  // aim at ~1024 blocks per launch, at least 4 per image.  The partition is free: the apply is elementwise.
+  int nb = nch;
+  if (p.nrec > 0) {
+    int want = 1024 / (p.B > 0 ? p.B : 1);
+    want = want < 4 ? 4 : want;
+    nb = nch < want ? nch : want;
+  }
+  const int pix = (p.HW + nb - 1) / nb;
+  dim3 grid((p.HW + pix - 1) / pix, p.B);
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((gn_apply_kernel<DT, PL>), grid, dim3(256), 0, stream, p, pix, nrec, pl.act));
   return hipGetLastError();
 }
 
