@@ -70,14 +70,23 @@ template <> struct T16<DT_BF16> {
 
 template <> struct T16<DT_FP16> {
   static __device__ __forceinline__ float tof(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  // The converted bits go through an empty asm: hipcc (fp-contract=fast) otherwise folds `x - tof(fromf(x))` with a
+  // producing multiply into v_fma_mix*_f16, which rounds the EXACT product to fp16, while the stored hi value is the
+  // fp16 rounding of the fp32-rounded product (v_cvt_pk_f16_f32) -- the two differ on fp16 ties (2^-14 of all values),
+  // and the hi/lo pair of an fp16x3 tensor then sums to a value one fp16 ulp off.  (Found on the attention output:
+  // 58 of 886 272 elements, each off by exactly 2^-13 or 2^-14.)
   static __device__ __forceinline__ uint16_t fromf(float f) {
     _Float16 h = (_Float16)f;
-    return __builtin_bit_cast(uint16_t, h);
+    uint32_t r = __builtin_bit_cast(uint16_t, h);
+    asm("" : "+v"(r));
+    return (uint16_t)r;
   }
   static __device__ __forceinline__ uint32_t pack2(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
     f16x2_t v = {(_Float16)a, (_Float16)b};
-    return __builtin_bit_cast(uint32_t, v);
+    uint32_t r = __builtin_bit_cast(uint32_t, v);
+    asm("" : "+v"(r));
+    return r;
   }
   static __device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),

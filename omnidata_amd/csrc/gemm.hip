@@ -422,47 +422,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
 
   int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k tile being LOADED (wave-uniform)
 
-  // ---- L2 prefetch stream (p.pf_dist = D > 0, single-plane kernels).  The k-loop keeps ONE k-tile in flight beside the
-  // one it multiplies (LDS capacity), so a tile that misses in L2 costs a full HBM/MALL latency per k-tile.  Thread t
-  // touches ONE dword of line t of the k-tile D tiles ahead ([BM rows of A | BN rows of W], 128 B each) with a 4-byte
-  // LDS-DMA into a scratch slot nobody reads: 64 distinct lines per wave-instruction, no VGPR destination; the line is in
-  // L2 by the time the real 16-byte DMA asks for it.  The counted wait at the top of the loop lets these stay in flight.
-  constexpr int PFP = PL == 1 ? (BM + BN + NT - 1) / NT : 0;  // prefetch instructions per wave and k-tile
-  const int pf_dist = PL == 1 ? p.pf_dist : 0;
-  int pky = 0, pkx = 0, pc0 = 0;
-  unsigned pf_off[PFP > 0 ? PFP : 1];
-  int pf_iy0[PFP > 0 ? PFP : 1], pf_ix0[PFP > 0 ? PFP : 1];
-  auto advance_tap = [&](int& ky_, int& kx_, int& c0_) {
-    if (p.k_tap_fast) {
-      if (++kx_ == p.ksz) { kx_ = 0; if (++ky_ == p.ksz) { ky_ = 0; c0_ += BK; } }
-    } else {
-      c0_ += BK;
-      if (c0_ >= p.Cin) { c0_ = 0; if (++kx_ == p.ksz) { kx_ = 0; ++ky_; } }
-    }
-  };
-  if (pf_dist > 0) {
-#pragma unroll
-    for (int i = 0; i < PFP; ++i) {
-      const int line = tid + i * NT;
-      pf_iy0[i] = 0; pf_ix0[i] = 0;
-      if (line < BM) {  // A row m0 + line
-        const int m = m0 + line;
-        const bool okm = m < p.M;
-        const int mm = okm ? m : 0;
-        int rem, ox;
-        const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
-        const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
-        pf_iy0[i] = okm ? oy * p.stride - p.pad_t : -0x40000000;
-        pf_ix0[i] = ox * p.stride - p.pad_l;
-        const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)pf_iy0[i] * p.Win + pf_ix0[i]) * p.a_pix_stride;
-        pf_off[i] = (unsigned)(okm ? e * 2 : 0);
-      } else {
-        pf_off[i] = line < BM + BN ? (unsigned)((long long)(n0 + line - BM) * p.ldw * 2) : OOB;
-      }
-    }
-    for (int j = 0; j < 1 + pf_dist; ++j) advance_tap(pky, pkx, pc0);
-  }
-
 #define DPTX_ISSUE_TILE(BUF, K0)                                                                                   \
   do {                                                                                                             \
     char* sa_ = smem + (BUF) * STAGE_BYTES + wave * 1024;                                                          \
@@ -510,49 +469,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
 
   const int nk = p.K / BK;
   DPTX_ISSUE_TILE(0, 0);
-  bool pf_pending = false;  // prefetch touches were issued after the last tile DMA (they may stay in flight)
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed (every wave waits for its own DMA, then the barrier publishes all of
     // them) and every wave is done reading the other stage, which the next DMA overwrites
-    if (PFP > 0 && pf_dist > 0) {
-      // counted wait: everything but the PFP youngest operations (VMEM operations retire in order); raw barrier --
-      // __syncthreads() would drain vmcnt(0).  LDS: a wave's fragment reads of tile kt-1 returned before its MFMAs
-      // issued, i.e. before it arrives here.
-      if (!pf_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (PFP == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (kt + 1 < nk) DPTX_ISSUE_TILE((kt + 1) & 1, (kt + 1) * BK);
-    if (PFP > 0 && pf_dist > 0) {
-      pf_pending = kt + 1 + pf_dist < nk;
-      if (pf_pending) {
-        char* scratch = smem + 2 * STAGE_BYTES + wave * 256;
-        const unsigned tap_ = (unsigned)(((pky * p.Win + pkx) * p.a_pix_stride + pc0) * 2);
-        const unsigned wk_ = (unsigned)((((pky * p.ksz + pkx) * p.Cin) + pc0) * 2);
-#pragma unroll
-        for (int i = 0; i < PFP; ++i) {
-          if (wave * 64 + i * NT < BM) {  // wave-uniform: this wave's 64 lines are A rows
-            const int iy = pf_iy0[i] + pky, ix = pf_ix0[i] + pkx;
-            const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)scratch, 4,
-                                                     valid ? pf_off[i] + tap_ : OOB, 0, 0, 0);
-          } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)scratch, 4,
-                                                     pf_off[i] == OOB ? OOB : pf_off[i] + wk_, 0, 0, 0);
-          }
-        }
-        advance_tap(pky, pkx, pc0);
-      }
-    }
     const char* sa = smem + (kt & 1) * STAGE_BYTES;
     mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, A_LO, B_LO, wm, wn, lr, lh, acc);
   }
 #undef DPTX_ISSUE_TILE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stray prefetch touches must not land in the C tile
   __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
   epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
@@ -698,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
 // --------------------------------------------------------------------------------- dispatch
 template <int BM, int BN, int PL>
 constexpr size_t gemm_smem_bytes() {
-  constexpr size_t stage = 2 * (size_t)PL * (BM + BN) * 128 + 2048;  // + 256 B of prefetch scratch per wave
+  constexpr size_t stage = 2 * (size_t)PL * (BM + BN) * 128;
   constexpr size_t ct_full = (size_t)BM * (BN + 4) * 4;
   constexpr size_t ct = ct_full > 160 * 1024 ? (size_t)64 * (BN + 4) * 4 : ct_full;  // slab epilogue (2 wave rows x 32)
   return stage > ct ? stage : ct;
@@ -812,6 +738,14 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
     if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= min_k && t256 >= 200 && t256 * 100 >= rounds * 256 * 85)
       return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
   }
+  if constexpr (PL == 2) {
+    // 3-MFMA modes are one block per CU (two planes of two stages = 128 KB of LDS); eight waves (2 x 4, wave tile
+    // 64 x 32) instead of four put two waves on every SIMD, so that one's fragment reads overlap the other's MFMAs:
+    // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md).  DPTX_X3_W8=0: four waves.
+    static int w8 = -1;
+    if (w8 < 0) { const char* t = getenv("DPTX_X3_W8"); w8 = t ? atoi(t) : 1; }
+    if (w8 && p.N % 128 == 0 && m128 * (p.N / 128) >= 200) return launch_cfg<DT, PL, 128, 128, 2, 4>(p, stream);
+  }
   // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
   // 128x64 by 2..10 %, whose second round is nearly empty
   if (p.N % 128 == 0 && m128 * (p.N / 128) >= 256) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
@@ -835,11 +769,6 @@ hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   p.a_rpi_rcp = 1.0f / (float)(p.a_rpi > 0 ? p.a_rpi : 1);
   p.wout_rcp = 1.0f / (float)(p.Wout > 0 ? p.Wout : 1);
-  {
-    static int pf = -1;  // DPTX_PF: L2 prefetch distance in k-tiles (0 = off)
-    if (pf < 0) { const char* t = getenv("DPTX_PF"); pf = t ? atoi(t) : 0; }
-    p.pf_dist = pf;
-  }
   if (p.gn_part != nullptr && (p.gn_hw % 32 != 0 || p.N % 32 != 0 || p.gn_cpg != p.N / 32 || p.gn_cpg < 2 || p.gn_cpg > 32 ||
                                (p.gn_cpg & (p.gn_cpg - 1)) != 0 || p.bias != nullptr || p.act != 0))
     return hipErrorInvalidValue;  // statistics are those of the raw accumulators: no bias / activation in front of a GroupNorm

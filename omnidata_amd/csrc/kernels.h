@@ -41,7 +41,6 @@ struct GemmParams {
   // of (sum, sum of squares) per 32-row block; gn_hw = rows per image (% 32 == 0), gn_cpg = N / 32 channels per group
   float* gn_part;
   int gn_hw, gn_blocks, gn_cpg;
-  int pf_dist;  // L2 prefetch distance in k-tiles (0 = off; filled in by launch_gemm from DPTX_PF / the default)
   float a_rpi_rcp, wout_rcp;  // 1 / a_rpi, 1 / Wout (filled in by launch_gemm: row -> (image, y, x) without integer division)
 };
 
