@@ -295,6 +295,21 @@ struct dptx_engine {
 
 namespace {
 
+// Makes cfg.device_id current for the duration of a C entry point and restores the caller's device afterwards (a process
+// that drives several GPUs keeps its own current device; torch.cuda.current_device() is not switched behind its back).
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
 #define HIPCHK(e, call)                                                                   \
   do {                                                                                    \
     hipError_t _r = (call);                                                               \
@@ -844,7 +859,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
 void dptx_destroy(dptx_handle h) {
   if (!h) return;
   if (h->cfg.device_id >= 0) {
-    (void)hipSetDevice(h->cfg.device_id);
+    DeviceGuard guard(h->cfg.device_id);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
@@ -876,7 +891,8 @@ int dptx_load_tensor(dptx_handle h, const char* ref_key, const float* host_fp32,
 }
 
 static int ensure_device_memory(dptx_handle h) {
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   if (!h->d_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, h->packed_bytes));
   if (!h->d_arena) HIPCHK(h, hipMalloc((void**)&h->d_arena, h->arena_bytes));
   return DPTX_OK;
@@ -889,6 +905,8 @@ int dptx_finalize_weights(dptx_handle h) {
   if (h->cfg.device_id < 0) return DPTX_OK;
   r = ensure_device_memory(h);
   if (r != DPTX_OK) return r;
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   HIPCHK(h, hipMemcpy(h->d_blob, h->host_blob.data(), h->packed_bytes, hipMemcpyHostToDevice));
   h->device_ready = true;
   h->staged.clear();  // fp32 staging copies are no longer needed
@@ -910,7 +928,8 @@ int dptx_export_packed_device(dptx_handle h, void* dst_dev, size_t bytes, void* 
   if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
   if (!h->device_ready) return h->fail(DPTX_E_INVALID, "export before weights are on the device");
   if (bytes < h->packed_bytes) return h->fail(DPTX_E_INVALID, "export buffer too small");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   HIPCHK(h, hipMemcpyAsync(dst_dev, h->d_blob, h->packed_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return DPTX_OK;
 }
@@ -921,6 +940,8 @@ int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, 
   if (bytes != h->packed_bytes) return h->fail(DPTX_E_INVALID, "packed blob size mismatch (different config/build?)");
   int r = ensure_device_memory(h);
   if (r != DPTX_OK) return r;
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   HIPCHK(h, hipMemcpyAsync(h->d_blob, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   h->device_ready = true;
   return DPTX_OK;
@@ -932,7 +953,8 @@ int dptx_enable_taps(dptx_handle h, int on) {
   if (!h) return DPTX_E_INVALID;
   if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
   if (on && !h->d_tok_taps) {
-    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
     HIPCHK(h, hipMalloc((void**)&h->d_tok_taps, (size_t)13 * h->tok_tap_stride * 4));
   }
   h->taps_on = on != 0;
@@ -986,6 +1008,7 @@ static int run_forward(dptx_handle h, const float* x, float* y, float* y2, int b
     HIPCHK(h, hipStreamWaitEvent(stream, h->ev_join[r], 0));
     first += (size_t)nb;
   }
+  h->taps.clear();  // stage taps describe whole-batch runs only (dptx_enable_taps makes the forward single-pass)
   h->launches = launches;
   h->last_batch = batch;
   return rc;
@@ -1002,7 +1025,8 @@ int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_d
   if (!h->device_ready) return h->fail(DPTX_E_INVALID, "dptx_forward before weights were finalized/imported");
   if (batch < 1 || batch > h->cfg.max_batch) return h->fail(DPTX_E_INVALID, "batch out of range [1, max_batch]");
   if (x_dtype != DPTX_IO_FP32) return h->fail(DPTX_E_INVALID, "unsupported x_dtype");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   if (height < 64 || width < 64 || height % 32 != 0 || width % 32 != 0)
     return h->fail(DPTX_E_INVALID, "input height/width must be multiples of 32, >= 64");
   if ((long long)height * width > (long long)h->max_h * h->max_w)
@@ -1023,7 +1047,8 @@ int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y
     return h->fail(DPTX_E_INVALID, "input height/width must be multiples of 32, >= 64");
   if ((long long)height * width > (long long)h->max_h * h->max_w)
     return h->fail(DPTX_E_INVALID, "input larger than the engine was planned for (dptx_config.max_height/max_width)");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   return run_forward(h, (const float*)x_dev, (float*)y_normal_dev, (float*)y_depth_dev, batch, height, width, (hipStream_t)stream);
 }
 
@@ -1035,7 +1060,8 @@ int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_f
   size_t n = 1;
   for (int i = 0; i < 4; ++i) { shape4[i] = t.shape[i]; n *= (size_t)t.shape[i]; }
   if (capacity_floats < n) return h->fail(DPTX_E_INVALID, "tap buffer too small");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   HIPCHK(h, hipDeviceSynchronize());
   if (t.fp32) {
     HIPCHK(h, hipMemcpy(dst_host, t.ptr, n * 4, hipMemcpyDeviceToHost));
@@ -1069,7 +1095,8 @@ int dptx_set_profiling(dptx_handle h, int on) {
 int dptx_profile_get(dptx_handle h, int32_t category, double* ms, int64_t* launches, double* macs_per_image) {
   if (!h || category < 0 || category > 3) return DPTX_E_INVALID;
   if (h->event_cat.empty()) return h->fail(DPTX_E_INVALID, "no profiled forward recorded");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   HIPCHK(h, hipEventSynchronize(h->events[h->event_cat.size()]));
   double t = 0.0;
   int64_t n = 0;
@@ -1089,7 +1116,8 @@ int dptx_profile_get(dptx_handle h, int32_t category, double* ms, int64_t* launc
 int dptx_profile_dump(dptx_handle h, const char* path) {
   if (!h || !path) return DPTX_E_INVALID;
   if (h->event_cat.empty()) return h->fail(DPTX_E_INVALID, "no profiled forward recorded");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
   HIPCHK(h, hipEventSynchronize(h->events[h->event_cat.size()]));
   FILE* fp = fopen(path, "w");
   if (!fp) return h->fail(DPTX_E_INVALID, std::string("cannot open ") + path);

@@ -98,8 +98,15 @@ def _ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    """hipStream_t of torch's current stream on `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check_out(out: torch.Tensor, shape, device):
+    if (out.dtype != torch.float32 or not out.is_contiguous() or out.device != device or tuple(out.shape) != tuple(shape)):
+        raise ValueError(f"out must be a contiguous float32 tensor of shape {tuple(shape)} on {device}, got "
+                         f"{out.dtype} {tuple(out.shape)} on {out.device} (contiguous={out.is_contiguous()})")
 
 
 class Engine:
@@ -166,13 +173,13 @@ class Engine:
 
     def export_packed(self) -> torch.Tensor:
         t = torch.empty(self.packed_bytes, dtype=torch.uint8, device=f"cuda:{self.cfg.device_id}")
-        self._check(self.lib.dptx_export_packed_device(self.h, t.data_ptr(), t.numel(), _stream()), "export_packed_device")
+        self._check(self.lib.dptx_export_packed_device(self.h, t.data_ptr(), t.numel(), _stream(t.device)), "export_packed_device")
         return t
 
     def import_packed(self, blob: torch.Tensor):
         assert blob.is_cuda and blob.dtype == torch.uint8 and blob.is_contiguous()
-        self._check(self.lib.dptx_import_packed_device(self.h, blob.data_ptr(), blob.numel(), _stream()), "import_packed_device")
-        torch.cuda.current_stream().synchronize()
+        self._check(self.lib.dptx_import_packed_device(self.h, blob.data_ptr(), blob.numel(), _stream(blob.device)), "import_packed_device")
+        torch.cuda.current_stream(blob.device).synchronize()
 
     # ---- packed-blob cache on disk: skips the fp32 fold / re-layout / upload-from-fp32 at start-up
     def _cache_meta(self) -> Dict[str, str]:
@@ -207,9 +214,13 @@ class Engine:
             raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32 (384x384 is the trained size), got {tuple(x.shape)}")
         x = x.contiguous().float()
         B, _, H, W = x.shape
+        if x.device.index != self.cfg.device_id:
+            raise RuntimeError(f"input is on {x.device}, the engine was created for cuda:{self.cfg.device_id}")
         if out is None:
             out = torch.empty(B, self.cfg.num_channels, H, W, dtype=torch.float32, device=x.device)
-        self._check(self.lib.dptx_forward_hw(self.h, x.data_ptr(), 0, out.data_ptr(), B, H, W, _stream()), "forward")
+        else:
+            _check_out(out, (B, self.cfg.num_channels, H, W), x.device)
+        self._check(self.lib.dptx_forward_hw(self.h, x.data_ptr(), 0, out.data_ptr(), B, H, W, _stream(x.device)), "forward")
         return out
 
     def forward_dual(self, x: torch.Tensor, out_normal: Optional[torch.Tensor] = None,
@@ -221,12 +232,18 @@ class Engine:
             raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32, got {tuple(x.shape)}")
         x = x.contiguous().float()
         B, _, H, W = x.shape
+        if x.device.index != self.cfg.device_id:
+            raise RuntimeError(f"input is on {x.device}, the engine was created for cuda:{self.cfg.device_id}")
         if out_normal is None:
             out_normal = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+        else:
+            _check_out(out_normal, (B, 3, H, W), x.device)
         if out_depth is None:
             out_depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+        else:
+            _check_out(out_depth, (B, 1, H, W), x.device)
         self._check(self.lib.dptx_forward_dual(self.h, x.data_ptr(), 0, out_normal.data_ptr(), out_depth.data_ptr(), B, H, W,
-                                               _stream()), "forward_dual")
+                                               _stream(x.device)), "forward_dual")
         return out_normal, out_depth
 
     def enable_taps(self, on: bool = True):
