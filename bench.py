@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--parity-dtype", default="mixed", help="mode timed and checked against the fp32 oracle next to --dtype "
                                                             "(N = 1 only); 'none' skips it")
     ap.add_argument("--parity-x3-groups", default="")
+    ap.add_argument("--io", default="fp32", choices=["fp32", "bf16", "fp16"], help="element type of the caller-side image and "
+                    "result tensors (SURVEY.md 8d config 2 feeds bf16; fp32 is the reference's drop-in convention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
@@ -84,10 +86,11 @@ def main():
     C = 1 if args.task == "depth" else 3
     make_sd = (lambda: random_dual_state_dict(0)) if dual else (lambda: random_state_dict(0, C))
     eng = build_replicated_engine(make_sd, C, args.batch, args.dtype, local_rank, dual=dual, x3_groups=args.x3_groups)
-    x = synthetic_input(1000 + rank, args.batch, "normal" if dual else args.task).to(device)
-    y = torch.empty(args.batch, C, 384, 384, dtype=torch.float32, device=device)
+    io_dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.io]
+    x = synthetic_input(1000 + rank, args.batch, "normal" if dual else args.task).to(device).to(io_dt)
+    y = torch.empty(args.batch, C, 384, 384, dtype=io_dt, device=device)
     if dual:  # one step = one encoder pass + both decoders on the batch
-        y2 = torch.empty(args.batch, 1, 384, 384, dtype=torch.float32, device=device)
+        y2 = torch.empty(args.batch, 1, 384, 384, dtype=io_dt, device=device)
         eng.forward = lambda x_, out=None: eng.forward_dual(x_, out_normal=out, out_depth=y2)
 
     def sync_all():
@@ -107,7 +110,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(y).all()
+    assert torch.isfinite(y.float()).all()
 
     # ---- roofline of the dominant kernel family: HIP events around every launch, separate passes
     roofline = None
@@ -234,7 +237,8 @@ def main():
                        "dual": "images/sec (384x384) DPT-Hybrid dual-task normal+depth, shared encoder"}[args.task],
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic 384x384 inputs resident in HBM; seeded random weights",
+            "vs_baseline": None, "dtype": args.dtype, "io_dtype": args.io,
+            "data": "synthetic 384x384 inputs resident in HBM; seeded random weights",
             "config": {"workload": f"DPT-Hybrid-384 {args.task}, batch {args.batch}/GPU, {args.dtype}, {world}xMI355X "
                                    f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"replicas x{world} (no collective in the loop)",

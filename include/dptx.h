@@ -57,8 +57,10 @@ enum { DPTX_GROUP_RESNET = 1,      /* stem + ResNetV2 stages (convs and GroupNor
        DPTX_GROUP_FUSION = 32,     /* scratch.refinenet4..1                                    */
        DPTX_GROUP_HEAD = 64,       /* scratch.output_conv                                      */
        DPTX_GROUP_ALL = 127 };
-/* dtype of caller-side image / result buffers */
-enum { DPTX_IO_FP32 = 0 };
+/* element type of the caller-side image AND result buffers of one forward call (`x_dtype`): fp32 is the drop-in default
+ * (the reference feeds and returns fp32 tensors); with BF16 / FP16 the stem reads and the head writes 16-bit NCHW
+ * tensors directly (SURVEY.md 8d config 2 feeds bf16) -- half the bytes at the boundary, no conversion pass. */
+enum { DPTX_IO_FP32 = 0, DPTX_IO_BF16 = 1, DPTX_IO_FP16 = 2 };
 
 typedef struct dptx_config {
   int32_t num_channels;  /* 3 = surface normals, 1 = depth (dpt_depth.py:88 num_channels)      */
@@ -117,9 +119,9 @@ int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, 
 size_t dptx_workspace_bytes(dptx_handle h);
 
 /* Replaces `DPTDepthModel.forward(x)` (dpt_depth.py:106-107 -> DPT.forward :67-85).
- *   x_dev : [batch,3,384,384] contiguous NCHW, x_dtype = DPTX_IO_FP32; normal model expects
+ *   x_dev : [batch,3,384,384] contiguous NCHW of x_dtype (DPTX_IO_FP32 / _BF16 / _FP16); normal model expects
  *           values in [0,1], depth model in [-1,1] (omnidata_tools/torch/README.md:46,49).
- *   y_dev : [batch,C,384,384] contiguous NCHW fp32 (for C=1 this is bit-identical to the
+ *   y_dev : [batch,C,384,384] contiguous NCHW of the same x_dtype (for C=1 this is bit-identical to the
  *           reference's squeezed [batch,384,384]); >= 0 when non_negative, NOT clamped to 1
  *           (callers clamp: demo.py:140).
  * Asynchronous on `stream` (a hipStream_t; NULL = default stream). 1 <= batch <= max_batch. */

@@ -187,6 +187,18 @@ __device__ __forceinline__ void relu8_planes(u32x4_t& hi, u32x4_t& lo) {
   hi = __builtin_bit_cast(u32x4_t, __builtin_elementwise_max(h, zero));
 }
 
+// caller-side image / result buffers (include/dptx.h DPTX_IO_*): 0 fp32, 1 bf16, 2 fp16
+constexpr int IO_FP32 = 0, IO_BF16 = 1, IO_FP16 = 2;
+__device__ __forceinline__ float io_load(const void* p, long long i, int io) {
+  if (io == IO_FP32) return ((const float*)p)[i];
+  const uint16_t u = ((const uint16_t*)p)[i];
+  return io == IO_BF16 ? T16<DT_BF16>::tof(u) : T16<DT_FP16>::tof(u);
+}
+__device__ __forceinline__ void io_store(void* p, long long i, float v, int io) {
+  if (io == IO_FP32) ((float*)p)[i] = v;
+  else ((uint16_t*)p)[i] = io == IO_BF16 ? T16<DT_BF16>::fromf(v) : T16<DT_FP16>::fromf(v);
+}
+
 // bilinear blend of a 2x2 neighbourhood in ATen's association, ly0*(lx0*a + lx1*b) + ly1*(lx0*c + lx1*d), with the
 // fused-multiply-adds spelled out so that every kernel that interpolates rounds identically
 __device__ __forceinline__ float bilerp(float a, float b, float c, float d, float lx0, float lx1, float ly0, float ly1) {

@@ -452,6 +452,7 @@ struct Run {
   hipStream_t st;
   int dt;
   int Hi = 384, Wi = 384;  // input size (multiples of 32)
+  int io = 0;              // element type of the caller's x / y buffers (DPTX_IO_*)
   size_t abase = 0;        // byte offset of this run's arena region
   bool half = false;       // half-batch plan (Buf::off2) instead of the whole-batch plan
   hipError_t err = hipSuccess;
@@ -528,10 +529,10 @@ struct Run {
     conv(tmp, H, W, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, W, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra);
   }
 
-  int forward(const float* x, float* y, float* y2);
+  int forward(const void* x, void* y, void* y2);
 };
 
-int Run::forward(const float* x, float* y, float* y2) {
+int Run::forward(const void* x, void* y, void* y2) {
   dptx_engine* E = e;
   E->taps.clear();
   E->event_cat.clear();
@@ -561,7 +562,7 @@ int Run::forward(const float* x, float* y, float* y2) {
 
   // ---- stem: fused conv7x7 s2 SAME (stem.hip, no im2col) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
   group(DPTX_GROUP_RESNET);
-  chk(launch_stem_conv(dt, x, E->w(bp + "stem.conv.weight"), A(E->sraw), B, Hi, Wi, E->pl, st), "stem.conv", 0);
+  chk(launch_stem_conv(dt, x, io, E->w(bp + "stem.conv.weight"), A(E->sraw), B, Hi, Wi, E->pl, st), "stem.conv", 0);
   exec_macs += (double)h2 * w2 * 64 * STEM_K;
   cat_macs[0] += (double)h2 * w2 * 64 * STEM_K;
   gn_stats(A(E->sraw), part0, h2 * w2, 64);
@@ -706,7 +707,7 @@ int Run::forward(const float* x, float* y, float* y2) {
 
   // one decoder = scratch.* of one task ("" -> scratch.*, "depth." -> depth.scratch.*); the dual-task engine runs two
   // on the same encoder outputs (S[0], S[1], L3, L4 are not modified by a decoder)
-  auto decode = [&](const std::string& pre, int ch, float* yout) {
+  auto decode = [&](const std::string& pre, int ch, void* yout) {
   // ---- scratch.layerN_rn (3x3, no bias) ---------------------------------------------------
   const void* rn_in[4] = {A(E->S[0]), A(E->S[1]), A(E->L3), A(E->L4)};
   const int rn_h[4] = {h4, Hi / 8, gh, h32};
@@ -752,7 +753,7 @@ int Run::forward(const float* x, float* y, float* y2) {
     // x2 upsample + conv 128->32 + ReLU + conv 1x1 + ReLU in one launch (head.hip): the 37.7 MB/image up-sampled map
     // and the 32-channel map never reach memory.  Not in bf16x3 mode, and not while stage taps are recorded ("h1").
     chk(launch_head_tail(dt, A(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"), E->f(oc + "4.weight"), E->f(oc + "4.bias"),
-                         yout, B, h2, w2, ch, E->cfg.non_negative, st),
+                         yout, io, B, h2, w2, ch, E->cfg.non_negative, st),
         "head.tail", 0);
     exec_macs += (double)Hi * Wi * 32 * 1152;
     cat_macs[0] += (double)Hi * Wi * 32 * (1152 + ch);
@@ -760,7 +761,7 @@ int Run::forward(const float* x, float* y, float* y2) {
     chk(launch_upsample2x(dt, A(E->H0), A(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
     conv(A(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, A(E->H1), E->f(oc + "2.bias"), 1, 0);
     tap((pre + "h1").c_str(), A(E->H1), Hi, Wi, 32);
-    chk(launch_head_out(dt, A(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, B, Hi * Wi, ch,
+    chk(launch_head_out(dt, A(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, io, B, Hi * Wi, ch,
                         E->cfg.non_negative, E->pl, st),
         "head.out");
   }
@@ -966,11 +967,13 @@ int dptx_enable_taps(dptx_handle h, int on) {
 // joined to the caller's stream with events.  Images are independent and every kernel is batch-invariant bit for bit, so
 // both schedules return the same bits; the second one lets the MFMA-bound launches of one half overlap the HBM-bound
 // launches and the tails of the other.
-static int run_forward(dptx_handle h, const float* x, float* y, float* y2, int batch, int height, int width, hipStream_t stream) {
+static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, int batch, int height, int width,
+                       hipStream_t stream) {
   const int C = h->cfg.num_channels;
+  const size_t esz = io == DPTX_IO_FP32 ? 4 : 2;  // bytes per element of the caller's buffers
   const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling;
   if (!split) {
-    Run run{h, batch, stream, h->cfg.dtype, height, width};
+    Run run{h, batch, stream, h->cfg.dtype, height, width, io};
     const int rc = run.forward(x, y, y2);
     h->launches = run.launches;
     h->exec_macs = run.exec_macs;
@@ -994,10 +997,11 @@ static int run_forward(dptx_handle h, const float* x, float* y, float* y2, int b
   for (int r = 0; r < nr; ++r) {
     const int nb = batch / nr + (r < batch % nr ? 1 : 0);
     HIPCHK(h, hipStreamWaitEvent(h->sub_stream[r], h->ev_fork, 0));
-    Run run{h, nb, h->sub_stream[r], h->cfg.dtype, height, width};
+    Run run{h, nb, h->sub_stream[r], h->cfg.dtype, height, width, io};
     run.abase = (size_t)r * h->half_region;
     run.half = true;
-    const int rr = run.forward(x + first * 3 * px, y + first * C * px, y2 ? y2 + first * px : nullptr);
+    const int rr = run.forward((const char*)x + first * 3 * px * esz, (char*)y + first * C * px * esz,
+                               y2 ? (char*)y2 + first * px * esz : nullptr);
     if (rc == DPTX_OK) rc = rr;
     launches += run.launches;
     if (r == 0) {
@@ -1024,7 +1028,8 @@ int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_d
   if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "dptx_forward on a host-only handle");
   if (!h->device_ready) return h->fail(DPTX_E_INVALID, "dptx_forward before weights were finalized/imported");
   if (batch < 1 || batch > h->cfg.max_batch) return h->fail(DPTX_E_INVALID, "batch out of range [1, max_batch]");
-  if (x_dtype != DPTX_IO_FP32) return h->fail(DPTX_E_INVALID, "unsupported x_dtype");
+  if (x_dtype != DPTX_IO_FP32 && x_dtype != DPTX_IO_BF16 && x_dtype != DPTX_IO_FP16)
+    return h->fail(DPTX_E_INVALID, "unsupported x_dtype (DPTX_IO_FP32 / DPTX_IO_BF16 / DPTX_IO_FP16)");
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
   if (height < 64 || width < 64 || height % 32 != 0 || width % 32 != 0)
@@ -1032,7 +1037,7 @@ int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_d
   if ((long long)height * width > (long long)h->max_h * h->max_w)
     return h->fail(DPTX_E_INVALID, "input larger than the engine was planned for (dptx_config.max_height/max_width)");
   if (h->cfg.dual_task) return h->fail(DPTX_E_INVALID, "dual-task handle: call dptx_forward_dual");
-  return run_forward(h, (const float*)x_dev, (float*)y_dev, nullptr, batch, height, width, (hipStream_t)stream);
+  return run_forward(h, x_dev, x_dtype, y_dev, nullptr, batch, height, width, (hipStream_t)stream);
 }
 
 int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_normal_dev, void* y_depth_dev, int32_t batch,
@@ -1042,14 +1047,15 @@ int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y
   if (!h->cfg.dual_task) return h->fail(DPTX_E_INVALID, "dptx_forward_dual needs a handle created with dual_task = 1");
   if (!h->device_ready) return h->fail(DPTX_E_INVALID, "dptx_forward_dual before weights were finalized/imported");
   if (batch < 1 || batch > h->cfg.max_batch) return h->fail(DPTX_E_INVALID, "batch out of range [1, max_batch]");
-  if (x_dtype != DPTX_IO_FP32) return h->fail(DPTX_E_INVALID, "unsupported x_dtype");
+  if (x_dtype != DPTX_IO_FP32 && x_dtype != DPTX_IO_BF16 && x_dtype != DPTX_IO_FP16)
+    return h->fail(DPTX_E_INVALID, "unsupported x_dtype (DPTX_IO_FP32 / DPTX_IO_BF16 / DPTX_IO_FP16)");
   if (height < 64 || width < 64 || height % 32 != 0 || width % 32 != 0)
     return h->fail(DPTX_E_INVALID, "input height/width must be multiples of 32, >= 64");
   if ((long long)height * width > (long long)h->max_h * h->max_w)
     return h->fail(DPTX_E_INVALID, "input larger than the engine was planned for (dptx_config.max_height/max_width)");
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
-  return run_forward(h, (const float*)x_dev, (float*)y_normal_dev, (float*)y_depth_dev, batch, height, width, (hipStream_t)stream);
+  return run_forward(h, x_dev, x_dtype, y_normal_dev, y_depth_dev, batch, height, width, (hipStream_t)stream);
 }
 
 int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_floats, int64_t shape4[4]) {
@@ -1150,7 +1156,7 @@ int dptx_op_gemm(int32_t dtype, const void* A, const void* W, const float* bias,
 
 int dptx_op_head_tail(int32_t dtype, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4, float* y,
                       int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t relu_out, void* stream) {
-  return launch_head_tail(dtype, H0, W2, b2, w4, b4, y, B, Hs, Ws, C, relu_out, (hipStream_t)stream) == hipSuccess ? DPTX_OK
+  return launch_head_tail(dtype, H0, W2, b2, w4, b4, y, DPTX_IO_FP32, B, Hs, Ws, C, relu_out, (hipStream_t)stream) == hipSuccess ? DPTX_OK
                                                                                                                 : DPTX_E_HIP;
 }
 
@@ -1170,7 +1176,7 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
 }
 
 int dptx_op_stem_conv(int32_t dtype, const float* x, const void* Wt, void* y, int32_t B, int32_t H, int32_t W, void* stream) {
-  return launch_stem_conv(dtype, x, Wt, y, B, H, W, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+  return launch_stem_conv(dtype, x, DPTX_IO_FP32, Wt, y, B, H, W, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
 int dptx_op_attention(int32_t dtype, const void* qkv, void* out, int32_t B, int32_t S, int32_t heads, void* stream) {

@@ -65,7 +65,7 @@ __device__ __forceinline__ u32x4_t vblend(const float (&T)[6][8], float ly0, flo
 template <int DT>
 __global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* __restrict__ H0, const uint16_t* __restrict__ W2,
                                                                const float* __restrict__ b2, const float* __restrict__ w4,
-                                                               const float* __restrict__ b4, float* __restrict__ y, int B,
+                                                               const float* __restrict__ b4, void* __restrict__ y, int io, int B,
                                                                int Hs, int Ws, int C, int relu_out, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Wl = smem;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* _
         s += __shfl_xor(s, 32);
         s += cst[128 + c];
         if (relu_out) s = fmaxf(s, 0.f);
-        if ((c & 1) == lh) y[(((long long)b * C + c) * Ho + oy) * Wo + ox0 + lr] = s;
+        if ((c & 1) == lh) io_store(y, (((long long)b * C + c) * Ho + oy) * Wo + ox0 + lr, s, io);
       }
     }
     __syncthreads();  // the window is rebuilt for the next tile
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* _
 }
 
 hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
-                            float* y, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream) {
+                            void* y, int io, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream) {
   if (mode_is_x3(mode) || C < 1 || C > 3 || (2 * Hs) % 8 != 0 || (2 * Ws) % 32 != 0) return hipErrorInvalidValue;
   const int ntiles = B * ((2 * Hs) / 8) * ((2 * Ws) / 32);
   static int cus = 0;
@@ -245,13 +245,13 @@ hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const floa
     auto k = head_tail_kernel<DT_BF16>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_SMEM); done = true; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(HT_THREADS), HT_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, B,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(HT_THREADS), HT_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, io, B,
                        Hs, Ws, C, relu_out, ntiles);
   } else {
     auto k = head_tail_kernel<DT_FP16>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_SMEM); done = true; }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(HT_THREADS), HT_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, B,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(HT_THREADS), HT_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, io, B,
                        Hs, Ws, C, relu_out, ntiles);
   }
   return hipGetLastError();

@@ -75,19 +75,21 @@ hipError_t launch_gn_relu_maxpool(int mode, const void* X, void* Y, const float*
                                   const float* partial, int B, int H, int W, int C, float eps, Planes pl, hipStream_t stream);
 
 // fused stem conv 7x7 s2 TF-SAME: x NCHW fp32 [B,3,H,W] -> y NHWC 16-bit [B,H/2,W/2,64]; Wt [64][176], k = (c*7+ky)*8 + kx
-hipError_t launch_stem_conv(int mode, const float* x, const void* Wt, void* y, int B, int H, int W, Planes pl, hipStream_t stream);
+// io: element type of x (common.h IO_*: fp32 / bf16 / fp16)
+hipError_t launch_stem_conv(int mode, const void* x, int io, const void* Wt, void* y, int B, int H, int W, Planes pl,
+                            hipStream_t stream);
 
 // bilinear x2 align_corners=True on NHWC 16-bit
 hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream);
 
 // y NCHW fp32 [B,Cout,HW] = act( W[Cout][32] * x[B*HW,32] + b ),  Cout <= 4
-hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, float* y, int B, int HW,
+hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, void* y, int io, int B, int HW,
                            int Cout, int relu, Planes pl, hipStream_t stream);
 
 // X[b*577] = cls + pos[0]  (fp32 token stream)
 // fused tail of the head: x2 bilinear -> conv3x3 128->32 -> ReLU -> conv1x1 32->C -> ReLU (head.hip; not in bf16x3 mode)
 hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
-                            float* y, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream);
+                            void* y, int io, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream);
 hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, int gw, int C, hipStream_t stream);
 hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, int S, int C, hipStream_t stream);
 

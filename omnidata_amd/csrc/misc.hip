@@ -54,8 +54,8 @@ hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int
 // dpt_depth.py:96-98.  X [B*HW][32] 16-bit (already ReLU'd) -> y NCHW fp32 [B][C][HW].
 template <int DT, int PL>
 __global__ __launch_bounds__(256) void head_out_kernel(const uint16_t* __restrict__ X, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int HW,
-                                                       int Cout, int relu, long long plane) {
+                                                       const float* __restrict__ bias, void* __restrict__ y, int io, int B,
+                                                       int HW, int Cout, int relu, long long plane) {
   const long long total = (long long)B * HW;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     float f[32];
@@ -67,17 +67,17 @@ __global__ __launch_bounds__(256) void head_out_kernel(const uint16_t* __restric
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc += w[c * 32 + k] * f[k];
       if (relu) acc = fmaxf(acc, 0.f);
-      y[(b * Cout + c) * HW + p] = acc;
+      io_store(y, (b * Cout + c) * HW + p, acc, io);
     }
   }
 }
 
-hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, float* y, int B, int HW, int Cout,
+hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, void* y, int io, int B, int HW, int Cout,
                            int relu, Planes pl, hipStream_t stream) {
   const long long total = (long long)B * HW;
   const int grid = (int)min((total + 255) / 256, (long long)16384);
   DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((head_out_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, w, b,
-                                              y, B, HW, Cout, relu, pl.act));
+                                              y, io, B, HW, Cout, relu, pl.act));
   return hipGetLastError();
 }
 

@@ -1,7 +1,7 @@
 // stem.hip -- fused 7x7 stride-2 TF-SAME stem convolution of the ResNetV2 hybrid backbone
 // (timm StdConv2dSame 3->64; vit.py:128-131 reaches it through patch_embed.backbone).
 //
-// x NCHW fp32 [B,3,H,W]  ->  y NHWC 16-bit [B,H/2,W/2,64]   (raw conv output; GroupNorm+ReLU+MaxPool follow)
+// x NCHW fp32 (or bf16 / fp16: DPTX_IO_*) [B,3,H,W]  ->  y NHWC 16-bit [B,H/2,W/2,64]   (raw conv output; GroupNorm+ReLU+MaxPool follow)
 //
 // No im2col buffer: a block owns 4 output rows x 64 output columns.  Its 13 x 133 x 3 input patch is converted to
 // 16-bit once and kept in LDS (10.6 KB); the implicit-GEMM K axis is ordered (c, ky, kx) with kx padded 7 -> 8, so
@@ -20,7 +20,7 @@ constexpr int ST_ROWS = 13, ST_PITCH = 136;  // patch rows, patch row pitch (ele
 constexpr int ST_PATCH = 3 * ST_ROWS * ST_PITCH;  // elements per plane
 
 template <int DT, int PL>
-__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restrict__ x, const uint16_t* __restrict__ Wt,
+__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const void* __restrict__ x, int io, const uint16_t* __restrict__ Wt,
                                                            uint16_t* __restrict__ y, int H, int W, int pad_t, int pad_l,
                                                            long long act_plane, long long w_plane) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -33,13 +33,13 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
   const int iy0 = 2 * oy0 - pad_t, ix0 = 2 * ox0 - pad_l;
 
   // ---- input patch -> LDS (zero outside the image and in the pitch padding)
-  const float* xb = x + (long long)b * 3 * H * W;
+  const long long xb = (long long)b * 3 * H * W;  // element offset of image b (x is fp32, bf16 or fp16: `io`)
   for (int i = tid; i < ST_PATCH; i += 256) {
     const int col = i % ST_PITCH, rc = i / ST_PITCH;
     const int r = rc % ST_ROWS, c = rc / ST_ROWS;
     const int iy = iy0 + r, ix = ix0 + col;
     float v = 0.f;
-    if (col < 134 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[((long long)c * H + iy) * W + ix];
+    if (col < 134 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = io_load(x, xb + ((long long)c * H + iy) * W + ix, io);
     const uint16_t hi = T16<DT>::fromf(v);
     patch[i] = hi;
     if (PL == 2) patch[ST_PATCH + i] = T16<DT>::fromf(v - T16<DT>::tof(hi));
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const float* __restri
   }
 }
 
-hipError_t launch_stem_conv(int mode, const float* x, const void* Wt, void* y, int B, int H, int W, Planes pl, hipStream_t stream) {
+hipError_t launch_stem_conv(int mode, const void* x, int io, const void* Wt, void* y, int B, int H, int W, Planes pl,
+                            hipStream_t stream) {
   const int Ho = H / 2, Wo = W / 2;
   if (H % 8 != 0 || W % 8 != 0) return hipErrorInvalidValue;
   const int pt = max((Ho - 1) * 2 + 7 - H, 0) / 2, plft = max((Wo - 1) * 2 + 7 - W, 0) / 2;
@@ -123,7 +124,7 @@ hipError_t launch_stem_conv(int mode, const float* x, const void* Wt, void* y, i
     auto k = stem_conv_kernel<DT, PL>;
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
-    hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, x, (const uint16_t*)Wt, (uint16_t*)y, H, W, pt, plft, pl.act, pl.w);
+    hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, x, io, (const uint16_t*)Wt, (uint16_t*)y, H, W, pt, plft, pl.act, pl.w);
   });
   return hipGetLastError();
 }

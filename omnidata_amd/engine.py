@@ -103,9 +103,12 @@ def _stream(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _check_out(out: torch.Tensor, shape, device):
-    if (out.dtype != torch.float32 or not out.is_contiguous() or out.device != device or tuple(out.shape) != tuple(shape)):
-        raise ValueError(f"out must be a contiguous float32 tensor of shape {tuple(shape)} on {device}, got "
+IO_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # include/dptx.h DPTX_IO_*
+
+
+def _check_out(out: torch.Tensor, shape, device, dtype=torch.float32):
+    if (out.dtype != dtype or not out.is_contiguous() or out.device != device or tuple(out.shape) != tuple(shape)):
+        raise ValueError(f"out must be a contiguous {dtype} tensor of shape {tuple(shape)} on {device}, got "
                          f"{out.dtype} {tuple(out.shape)} on {out.device} (contiguous={out.is_contiguous()})")
 
 
@@ -212,15 +215,18 @@ class Engine:
             raise RuntimeError("dptx forward needs a CUDA(HIP) tensor; there is no CPU fallback")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32 (384x384 is the trained size), got {tuple(x.shape)}")
-        x = x.contiguous().float()
+        if x.dtype not in IO_DTYPES:  # fp32 (the reference's convention), bf16 and fp16 images are read as they are
+            x = x.float()
+        x = x.contiguous()
         B, _, H, W = x.shape
         if x.device.index != self.cfg.device_id:
             raise RuntimeError(f"input is on {x.device}, the engine was created for cuda:{self.cfg.device_id}")
-        if out is None:
-            out = torch.empty(B, self.cfg.num_channels, H, W, dtype=torch.float32, device=x.device)
+        if out is None:  # the result comes back in the input's element type
+            out = torch.empty(B, self.cfg.num_channels, H, W, dtype=x.dtype, device=x.device)
         else:
-            _check_out(out, (B, self.cfg.num_channels, H, W), x.device)
-        self._check(self.lib.dptx_forward_hw(self.h, x.data_ptr(), 0, out.data_ptr(), B, H, W, _stream(x.device)), "forward")
+            _check_out(out, (B, self.cfg.num_channels, H, W), x.device, x.dtype)
+        self._check(self.lib.dptx_forward_hw(self.h, x.data_ptr(), IO_DTYPES[x.dtype], out.data_ptr(), B, H, W,
+                                             _stream(x.device)), "forward")
         return out
 
     def forward_dual(self, x: torch.Tensor, out_normal: Optional[torch.Tensor] = None,
@@ -230,19 +236,21 @@ class Engine:
             raise RuntimeError("dptx forward needs a CUDA(HIP) tensor; there is no CPU fallback")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32, got {tuple(x.shape)}")
-        x = x.contiguous().float()
+        if x.dtype not in IO_DTYPES:
+            x = x.float()
+        x = x.contiguous()
         B, _, H, W = x.shape
         if x.device.index != self.cfg.device_id:
             raise RuntimeError(f"input is on {x.device}, the engine was created for cuda:{self.cfg.device_id}")
         if out_normal is None:
-            out_normal = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+            out_normal = torch.empty(B, 3, H, W, dtype=x.dtype, device=x.device)
         else:
-            _check_out(out_normal, (B, 3, H, W), x.device)
+            _check_out(out_normal, (B, 3, H, W), x.device, x.dtype)
         if out_depth is None:
-            out_depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+            out_depth = torch.empty(B, 1, H, W, dtype=x.dtype, device=x.device)
         else:
-            _check_out(out_depth, (B, 1, H, W), x.device)
-        self._check(self.lib.dptx_forward_dual(self.h, x.data_ptr(), 0, out_normal.data_ptr(), out_depth.data_ptr(), B, H, W,
+            _check_out(out_depth, (B, 1, H, W), x.device, x.dtype)
+        self._check(self.lib.dptx_forward_dual(self.h, x.data_ptr(), IO_DTYPES[x.dtype], out_normal.data_ptr(), out_depth.data_ptr(), B, H, W,
                                                _stream(x.device)), "forward_dual")
         return out_normal, out_depth
 

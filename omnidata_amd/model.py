@@ -21,6 +21,11 @@ from .weights import (compose_dual_state_dict, dual_state_dict_spec, random_dual
                       read_checkpoint, state_dict_spec)
 
 
+def _io_dtype(x: torch.Tensor) -> torch.dtype:
+    """Result element type: the input's when the engine reads it directly (fp32 / bf16 / fp16), else fp32."""
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
+
+
 class _Node(nn.Module):
     """Anonymous container so that nested parameter names equal the reference's keys."""
 
@@ -131,7 +136,7 @@ class DPTDepthModel(BaseModel):
         if B <= step:
             y = eng.forward(x)
         else:
-            y = torch.empty(B, self.num_channels, H, W, dtype=torch.float32, device=x.device)
+            y = torch.empty(B, self.num_channels, H, W, dtype=_io_dtype(x), device=x.device)
             for i in range(0, B, step):
                 eng.forward(x[i:i + step], out=y[i:i + step])
         return y.squeeze(dim=1)  # dpt_depth.py:106-107
@@ -217,8 +222,8 @@ class DPTDualTaskModel(nn.Module):
             self.max_hw = (H, W)
         eng = self._get_engine(x.device)
         step = self._chunk()
-        yn = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
-        yd = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+        yn = torch.empty(B, 3, H, W, dtype=_io_dtype(x), device=x.device)
+        yd = torch.empty(B, 1, H, W, dtype=_io_dtype(x), device=x.device)
         for i in range(0, B, step):
             eng.forward_dual(x[i:i + step], out_normal=yn[i:i + step], out_depth=yd[i:i + step])
         return yn, yd.squeeze(dim=1)

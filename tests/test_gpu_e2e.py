@@ -120,6 +120,27 @@ def test_engine_vs_reference_golden(path, dtype):
     assert np.abs(row - g["out_row"]).max() < tol[0]
 
 
+@pytest.mark.parametrize("io", [torch.bfloat16, torch.float16])
+def test_sixteen_bit_caller_io(io):
+    """DPTX_IO_BF16 / _FP16 (SURVEY.md 8d config 2 feeds bf16): the stem reads and the head writes 16-bit NCHW tensors.
+    Feeding the 16-bit image must equal feeding its fp32 copy bit for bit before the output rounding, i.e. the 16-bit
+    result is exactly the rounding of the fp32 result -- and it is held to the same budget against the oracle."""
+    sd = random_state_dict(0, 3)
+    model = DPTDepthModel(num_channels=3, dtype="bf16", max_batch=3)
+    model.load_state_dict(sd)
+    model.to(DEV)
+    x16 = synthetic_input(2, 3, "normal").to(io)
+    y16 = model(x16.to(DEV))
+    assert y16.dtype == io and y16.shape == (3, 3, 384, 384)
+    y32 = model(x16.float().to(DEV))
+    assert y32.dtype == torch.float32
+    assert torch.equal(y16, y32.to(io))
+    oracle_threads()
+    ref = dpt_forward(sd, x16.float())
+    d = (y32.cpu() - ref).abs()
+    assert d.max() < E2E_TOL["bf16"][0] and d.pow(2).mean().sqrt() < E2E_TOL["bf16"][1]
+
+
 def test_deterministic_and_batch_invariant():
     """Size-independent properties at the benchmark batch: two runs are bit-identical (no atomics),
     and image i of a batch of 32 equals the same image run alone."""
