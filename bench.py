@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--task", default="normal", choices=["normal", "depth", "dual"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "bf16x3", "fp16x3", "mixed"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "bf16x3", "fp16x3", "mixed", "fp8"])
     ap.add_argument("--x3-groups", default="", help="dtype mixed: layer groups that run 3 MFMAs per product, e.g. resnet+embed "
                                                     "(default: everything but the ViT blocks)")
     ap.add_argument("--parity-dtype", default="mixed", help="mode timed and checked against the fp32 oracle next to --dtype "

@@ -45,7 +45,15 @@ enum { DPTX_DTYPE_BF16 = 0, DPTX_DTYPE_FP16 = 1, DPTX_DTYPE_BF16X3 = 2,
        /* FP16X3: the same hi/lo scheme with fp16 planes (hi = fp16(x) is also a valid single-pass fp16 operand).
         * MIXED : fp16 planes; the layer groups named in dptx_config.x3_groups run with 3 MFMAs per product, the others
         *         single-pass fp16 on the hi plane -- a per-layer precision policy (profiles/r02_precision_frontier.md). */
-       DPTX_DTYPE_FP16X3 = 3, DPTX_DTYPE_MIXED = 4 };
+       DPTX_DTYPE_FP16X3 = 3, DPTX_DTYPE_MIXED = 4,
+       /* FP8 (BASELINE.json configs[4] "fp8 MFMA weights"): a bf16 engine whose decoder convolutions -- the RCU 3x3 convs,
+        *         out_conv and the first head conv: 31 % of a single-task forward's MACs, 43 % of the dual-task one's --
+        *         run on OCP e4m3 operands (weights quantised at load time after a per-layer power-of-two scale, activations
+        *         quantised by their producers' epilogues) on v_mfma_scale_f32_32x32x64_f8f6f4 at unit block scale, fp32
+        *         accumulate.  Half the operand bytes per flop and twice the MFMA rate of bf16; per-conv error ~3 % rms
+        *         (4-bit significand) -- a throughput mode with its own stated tolerance, NOT a parity mode
+        *         (tests/test_gpu_fp8.py, profiles/r02_precision_frontier.md). */
+       DPTX_DTYPE_FP8 = 5 };
 /* layer groups of the forward for dptx_config.x3_groups (dtype = DPTX_DTYPE_MIXED).  A 3-MFMA group may only read
  * tensors produced by 3-MFMA groups (its lo planes must exist): HEAD needs FUSION needs RN needs RESNET and REASSEMBLE;
  * EMBED needs RESNET; the 12 ViT blocks exchange only the fp32 token stream and are free.  dptx_create rejects others. */
@@ -230,6 +238,12 @@ int dptx_op_layernorm(int32_t dtype, const float* x, const float* gamma, const f
 int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const float* beta,
                       const void* R, void* Y, int32_t B, int32_t HW, int32_t C, int32_t relu,
                       float eps, void* scratch_f32, void* stream);
+/* NHWC conv on OCP e4m3 operands (the fp8 dtype's convolution): X8[B,H,W,Cin] and Wt8[Cout][k][k][Cin] are e4m3 bytes
+ * (Cin % 128 == 0), fp32 accumulate on the block-scaled fp8 MFMA at unit scale; Y = act(out_scale * conv + bias) (+R) in
+ * bf16; Y8 (optional) receives the e4m3 copy of Y (ReLU'd first when q_relu). */
+int dptx_op_conv_fp8(const void* X8, const void* Wt8, const float* bias, const void* R, void* Y, void* Y8, int32_t B,
+                     int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad_t,
+                     int32_t pad_l, int32_t Ho, int32_t Wo, int32_t act, int32_t q_relu, float out_scale, void* stream);
 /* Bias-free convolution followed by GroupNorm(32) (+ residual R, + ReLU) the way the ResNetV2 stages run it: the
  * statistics come out of the conv's GEMM epilogue (fp32 accumulators, one record per 32-row block and group, fixed
  * order), the apply pass normalises the stored 16-bit map.  Yraw receives the conv output, Y the normalised result

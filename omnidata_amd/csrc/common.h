@@ -16,6 +16,7 @@ typedef short s16x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int DT_BF16 = 0;
 constexpr int DT_FP16 = 1;
+constexpr int DT_FP8 = 2;  // OCP e4m3 MFMA operands (GEMM A / W only; everything stored stays bf16 + an fp8 copy)
 
 // Precision modes of the engine ("dtype" in the C ABI):
 //   0 bf16, 1 fp16 : one 16-bit value per element, one MFMA per product.
@@ -29,7 +30,11 @@ constexpr int DT_FP16 = 1;
 //                    ("mixed" dtype of the C ABI: dptx_config.x3_groups) without converting tensors in between.
 //                    gfx950's f16 MFMA keeps subnormal inputs (tests/test_gpu_mixed.py pins that), so lo planes that
 //                    fall below 2^-14 still carry their bits (spacing 2^-24).
-constexpr int MODE_BF16 = 0, MODE_FP16 = 1, MODE_BF16X3 = 2, MODE_FP16X3 = 3;
+//   4 fp8 (GEMM only): A and W are OCP e4m3 bytes (128 of them per 128-byte k-tile row: half the bytes per flop of the
+//                    16-bit kernels), products on the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales
+//                    (2x the bf16 MFMA rate), fp32 accumulate; C / residuals bf16.  The engine's "fp8" dtype runs the
+//                    decoder's RCU / out_conv / head convolutions this way and everything else in bf16.
+constexpr int MODE_BF16 = 0, MODE_FP16 = 1, MODE_BF16X3 = 2, MODE_FP16X3 = 3, MODE_FP8 = 4;
 __host__ __device__ constexpr bool mode_is_x3(int mode) { return mode == MODE_BF16X3 || mode == MODE_FP16X3; }
 #define DPTX_DISPATCH_MODE(mode, ...)                                         \
   switch (mode) {                                                             \
@@ -185,6 +190,19 @@ __device__ __forceinline__ void relu8_planes(u32x4_t& hi, u32x4_t& lo) {
   const s16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
   lo = __builtin_bit_cast(u32x4_t, (s16x8_t)(__builtin_bit_cast(s16x8_t, lo) & ~neg));
   hi = __builtin_bit_cast(u32x4_t, __builtin_elementwise_max(h, zero));
+}
+
+// 8 floats -> 8 OCP e4m3 bytes (RNE, saturating at +-448); v_cvt_pk_fp8_f32 packs two floats into one half of a dword
+__device__ __forceinline__ uint2 pack_fp8x8(const float* f) {
+  float c[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c[e] = fminf(fmaxf(f[e], -448.f), 448.f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return make_uint2((uint32_t)lo, (uint32_t)hi);
 }
 
 // caller-side image / result buffers (include/dptx.h DPTX_IO_*): 0 fp32, 1 bf16, 2 fp16

@@ -88,6 +88,26 @@ inline float fp16_to_f32(uint16_t h) {
   return f;
 }
 
+// OCP e4m3 (fp8 "fn": bias 7, 3 mantissa bits, max 448, no infinities), round to nearest even, saturating
+inline uint8_t f32_to_e4m3(float f) {
+  if (f != f) return 0x7f;
+  const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+  double a = std::fabs((double)f);
+  if (a >= 448.0) return sign | 0x7e;
+  if (a < std::ldexp(1.0, -10)) return sign;  // below half of the smallest subnormal (2^-9)
+  int e;
+  (void)std::frexp(a, &e);  // a = m * 2^e, m in [0.5, 1)
+  e -= 1;                   // a = (1.xxx) * 2^e
+  if (e < -6) {             // subnormal: multiples of 2^-9
+    const int q = (int)std::nearbyint(std::ldexp(a, 9));
+    return sign | (uint8_t)q;  // q == 8 is the smallest normal (exp field 1, mantissa 0): the same bit pattern
+  }
+  int m = (int)std::nearbyint((std::ldexp(a, -e) - 1.0) * 8.0);
+  if (m == 8) { m = 0; ++e; }
+  if (e > 8) return sign | 0x7e;
+  return sign | (uint8_t)(((e + 7) << 3) | m);
+}
+
 // --------------------------------------------------------------------------- weight spec
 enum Role { R_STDCONV, R_CONV, R_LINEAR, R_VEC, R_HEAD4, R_UNUSED };
 struct Spec {
@@ -247,11 +267,27 @@ struct dptx_engine {
   bool taps_on = false;
   // kernel mode (common.h MODE_*) of a layer group: the engine dtype, or -- MIXED -- fp16x3 / fp16 per dptx_config.x3_groups
   int mode_of(int group) const {
+    if (cfg.dtype == DPTX_DTYPE_FP8) return MODE_BF16;  // fp8 GEMMs are launched explicitly (Run::conv), the rest is bf16
     if (cfg.dtype != DPTX_DTYPE_MIXED) return cfg.dtype;
     return (cfg.x3_groups & group) ? MODE_FP16X3 : MODE_FP16;
   }
-  bool two_planes() const { return cfg.dtype == DPTX_DTYPE_BF16X3 || cfg.dtype == DPTX_DTYPE_FP16X3 || cfg.dtype == DPTX_DTYPE_MIXED; }
-  bool bf16_storage() const { return cfg.dtype == DPTX_DTYPE_BF16 || cfg.dtype == DPTX_DTYPE_BF16X3; }
+  bool fp8() const { return cfg.dtype == DPTX_DTYPE_FP8; }
+  // fp8: the second plane of the arena / blob holds the e4m3 copies (byte offset off / 2 inside it) instead of lo planes
+  bool two_planes() const {
+    return cfg.dtype == DPTX_DTYPE_BF16X3 || cfg.dtype == DPTX_DTYPE_FP16X3 || cfg.dtype == DPTX_DTYPE_MIXED || fp8();
+  }
+  bool bf16_storage() const { return cfg.dtype == DPTX_DTYPE_BF16 || cfg.dtype == DPTX_DTYPE_BF16X3 || fp8(); }
+  // convolutions that run on e4m3 operands in the fp8 dtype: the decoder's RCU convs, out_conv and the first head conv
+  static bool fp8_weight(const std::string& key) {
+    return key.find("scratch.") != std::string::npos && key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 &&
+           (key.find("resConfUnit") != std::string::npos || key.find("out_conv") != std::string::npos ||
+            key.find("output_conv.0.") != std::string::npos);
+  }
+  std::vector<float> w_scale;  // per spec entry: 1 / (power-of-two scale applied before e4m3 quantisation); 0 = no fp8 copy
+  size_t scale_table_off() const { return 2 * packed_single; }
+  const void* w8(const std::string& key) const { return d_blob + packed_single + packed_off.at(key) / 2; }
+  float wscale(const std::string& key) const { return w_scale[spec_index.at(key)]; }
+  void* q8(const void* p) const { return d_arena + arena_single + ((const char*)p - d_arena) / 2; }  // e4m3 copy of an arena tensor
   // fused head tail (head.hip): single-plane head, no stage taps wanted; DPTX_HEAD_FUSED=0 keeps the three launches
   bool head_fused() const {
     static int env = -1;
@@ -385,7 +421,8 @@ int pack_host(dptx_engine* e) {
   if (!missing.empty()) return e->fail(DPTX_E_KEY, "missing tensors (strict load): " + missing);
   e->host_blob.assign(e->packed_bytes, 0);
   const bool bf = e->bf16_storage();
-  const bool x3 = e->two_planes();
+  const bool x3 = e->two_planes() && !e->fp8();
+  e->w_scale.assign(e->spec.size(), 0.f);
   const size_t lo_elems = e->packed_single / 2;  // uint16 distance hi -> lo plane
   auto bf16_to_f32 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
   // writes element i of a 16-bit tensor (and its lo plane in bf16x3 mode)
@@ -441,6 +478,31 @@ int pack_host(dptx_engine* e) {
           }
     }
   }
+  if (e->fp8()) {
+    // e4m3 copies of the fp8 layers' weights (same [O][kh][kw][I] order as the bf16 copy, one byte per element, second
+    // plane of the blob) quantised after a per-layer power-of-two scale that puts max|w| in [224, 448); the GEMM epilogue
+    // multiplies by its inverse.  The inverses travel in a table behind the two planes (ranks that import the blob).
+    for (size_t si = 0; si < e->spec.size(); ++si) {
+      const Spec& sp = e->spec[si];
+      if (sp.role != R_CONV || !dptx_engine::fp8_weight(sp.key)) continue;
+      const size_t n = numel(sp.shape), off = e->packed_off.at(sp.key);
+      const std::vector<float>& src = e->staged.at(sp.key);
+      const int O = (int)sp.shape[0], I = (int)sp.shape[1], KH = (int)sp.shape[2], KW = (int)sp.shape[3];
+      float mx = 0.f;
+      for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(src[i]));
+      const int k = mx > 0.f ? (int)std::floor(std::log2(224.0 / (double)mx)) : 0;
+      const float sc = std::ldexp(1.0f, k);
+      uint8_t* d8 = e->host_blob.data() + e->packed_single + off / 2;
+      for (int o = 0; o < O; ++o)
+        for (int ky = 0; ky < KH; ++ky)
+          for (int kx = 0; kx < KW; ++kx)
+            for (int i = 0; i < I; ++i)
+              d8[(size_t)o * I * KH * KW + ((size_t)ky * KW + kx) * I + i] =
+                  f32_to_e4m3(src[(((size_t)o * I + i) * KH + ky) * KW + kx] * sc);
+      e->w_scale[si] = 1.0f / sc;
+    }
+    memcpy(e->host_blob.data() + e->scale_table_off(), e->w_scale.data(), e->w_scale.size() * 4);
+  }
   e->finalized = true;
   return DPTX_OK;
 }
@@ -487,9 +549,13 @@ struct Run {
   // kernels.h GemmParams::gn_part); the caller checked gn_fusable(Hout * Wout)
   void conv(const void* in, int Hin, int Win, int Cin, const std::string& wkey, int ksz, int stride, int pad_t, int pad_l,
             int Hout, int Wout, int Cout, void* out, const float* bias, int act, int a_relu, const void* R1 = nullptr,
-            const void* R2 = nullptr, float* gn_part = nullptr) {
+            const void* R2 = nullptr, float* gn_part = nullptr, int q = 0) {
+    // fp8 dtype: q = 1 / 2 also writes the e4m3 copy of the output (2: ReLU'd, for consumers that pre-activate); a conv
+    // whose weight has an e4m3 copy runs on the fp8 MFMA, reading the e4m3 copy of `in` (ReLU'd by its producer)
+    const bool f8 = e->fp8() && dptx_engine::fp8_weight(wkey);
     GemmParams p{};
     p.A = in; p.W = e->w(wkey); p.C = out; p.bias = bias; p.R1 = R1; p.R2 = R2;
+    if (e->fp8() && q) { p.C8 = e->q8(out); p.q_relu = q == 2; }
     p.M = B * Hout * Wout; p.N = Cout; p.K = ksz * ksz * Cin; p.ldw = p.K;
     p.a_rpi = Hout * Wout; p.Wout = Wout; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.a_pix_stride = Cin;
     p.a_img_stride = (long long)Hin * Win * Cin; p.a_off = 0;
@@ -499,9 +565,12 @@ struct Run {
     p.act = act; p.a_relu = a_relu; p.planes = e->pl;
     p.k_tap_fast = (ksz == 3 && Cin >= 512) ? 1 : 0;  // measured per layer: profiles/r01_experiments.md
     if (gn_part) { p.gn_part = gn_part; p.gn_hw = Hout * Wout; p.gn_blocks = Hout * Wout / 32; p.gn_cpg = Cout / 32; }
+    if (f8) {
+      p.A = e->q8(in); p.W = e->w8(wkey); p.a_bytes /= 2; p.a_relu = 0; p.out_scale = e->wscale(wkey);
+    }
     exec_macs += (double)p.M / B * p.N * p.K;
     cat_macs[0] += (double)p.M / B * p.N * p.K;
-    chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
+    chk(launch_gemm(f8 ? MODE_FP8 : dt, p, st), wkey.c_str(), 0);
   }
 
   // GroupNorm statistics come out of the producing conv's epilogue when an image's rows are whole 32-row MFMA blocks
@@ -524,9 +593,11 @@ struct Run {
   }
 
   // RCU (blocks.py:263-286): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
-  void rcu(const std::string& p, const void* x, int H, int W, void* tmp, void* out, const void* extra) {
-    conv(x, H, W, FEAT, p + "conv1.weight", 3, 1, 1, 1, H, W, FEAT, tmp, e->f(p + "conv1.bias"), /*act*/ 1, /*a_relu*/ 1);
-    conv(tmp, H, W, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, W, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra);
+  // q_out (fp8 dtype): e4m3 copy of the unit's output -- 2 when its consumer pre-activates (another RCU), 1 otherwise
+  void rcu(const std::string& p, const void* x, int H, int W, void* tmp, void* out, const void* extra, int q_out) {
+    conv(x, H, W, FEAT, p + "conv1.weight", 3, 1, 1, 1, H, W, FEAT, tmp, e->f(p + "conv1.bias"), /*act*/ 1, /*a_relu*/ 1, nullptr,
+         nullptr, nullptr, 1);
+    conv(tmp, H, W, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, W, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra, nullptr, q_out);
   }
 
   int forward(const void* x, void* y, void* y2);
@@ -717,7 +788,7 @@ int Run::forward(const void* x, void* y, void* y2) {
   group(DPTX_GROUP_RN);
   for (int i = 0; i < 4; ++i) {
     conv(rn_in[i], rn_h[i], rn_w[i], rn_c[i], pre + "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
-         rn_w[i], FEAT, A(E->lrn[i]), nullptr, 0, 0);
+         rn_w[i], FEAT, A(E->lrn[i]), nullptr, 0, 0, nullptr, nullptr, nullptr, /*q: every consumer pre-activates*/ 2);
     tap((pre + rn_names[i]).c_str(), A(E->lrn[i]), rn_h[i], rn_w[i], FEAT);
   }
 
@@ -734,12 +805,14 @@ int Run::forward(const void* x, void* y, void* y2) {
     if (i == 4) {
       sum = A(E->lrn[3]);
     } else {
-      rcu(p + "resConfUnit1.", A(E->lrn[i - 1]), h, w, A(E->tA), A(E->tB), path);  // tB = path + RCU1(lrn)
+      rcu(p + "resConfUnit1.", A(E->lrn[i - 1]), h, w, A(E->tA), A(E->tB), path, 2);  // tB = path + RCU1(lrn)
       sum = A(E->tB);
     }
-    rcu(p + "resConfUnit2.", sum, h, w, A(E->tA), A(E->tC), nullptr);
+    rcu(p + "resConfUnit2.", sum, h, w, A(E->tA), A(E->tC), nullptr, 1);
     conv(A(E->tC), h, w, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, w, FEAT, A(E->tA), E->f(p + "out_conv.bias"), 0, 0);
-    chk(launch_upsample2x(dt, A(E->tA), A(E->P[i - 1]), B, h, w, FEAT, E->pl, st), "fusion.up");
+    // path_1 feeds the first head conv: in the fp8 dtype the up-sampling also writes its e4m3 copy
+    chk(launch_upsample2x(dt, A(E->tA), A(E->P[i - 1]), B, h, w, FEAT, E->pl, st, (E->fp8() && i == 1) ? E->q8(A(E->P[0])) : nullptr),
+        "fusion.up");
     path = A(E->P[i - 1]);
     tap((pre + p_names[i - 1]).c_str(), path, 2 * h, 2 * w, FEAT);
   }
@@ -807,7 +880,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (cfg->streams < 0 || cfg->streams > 4) return DPTX_E_INVALID;
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
-      cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_MIXED || (cfg->ws_form != 0 && cfg->ws_form != 1))
+      cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_FP8 || (cfg->ws_form != 0 && cfg->ws_form != 1))
     return DPTX_E_INVALID;
   int x3_groups = 0;
   if (cfg->dtype == DPTX_DTYPE_MIXED) {
@@ -842,7 +915,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
     }
   }
   e->packed_single = off;
-  e->packed_bytes = off * (e->two_planes() ? 2 : 1);
+  e->packed_bytes = off * (e->two_planes() ? 2 : 1) + (e->fp8() ? align_up(e->spec.size() * 4, 256) : 0);
   e->pl.w = e->two_planes() ? (long long)(off / 2) : 0;
   plan_arena(e);
   if (cfg->device_id >= 0) {
@@ -944,6 +1017,12 @@ int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, 
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
   HIPCHK(h, hipMemcpyAsync(h->d_blob, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (h->fp8()) {  // the per-layer output scales are launch parameters: read them back from the blob's table
+    h->w_scale.assign(h->spec.size(), 0.f);
+    HIPCHK(h, hipMemcpyAsync(h->w_scale.data(), h->d_blob + h->scale_table_off(), h->spec.size() * 4, hipMemcpyDeviceToHost,
+                             (hipStream_t)stream));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  }
   h->device_ready = true;
   return DPTX_OK;
 }
@@ -1197,6 +1276,21 @@ int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const fl
   g.X = X; g.Y = Y; g.gamma = gamma; g.beta = beta; g.partial = (float*)scratch_f32; g.R = R;
   g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = eps;
   return launch_gn_apply(dtype, g, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_conv_fp8(const void* X8, const void* Wt8, const float* bias, const void* R, void* Y, void* Y8, int32_t B, int32_t H,
+                     int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
+                     int32_t Wo, int32_t act, int32_t q_relu, float out_scale, void* stream) {
+  GemmParams p{};
+  p.A = X8; p.W = Wt8; p.C = Y; p.bias = bias; p.R1 = R; p.C8 = Y8; p.q_relu = q_relu; p.out_scale = out_scale;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = ksize * ksize * Cin; p.ldw = p.K;
+  p.a_rpi = Ho * Wo; p.Wout = Wo; p.Hin = H; p.Win = W; p.Cin = Cin; p.a_pix_stride = Cin;
+  p.a_img_stride = (long long)H * W * Cin;
+  p.a_bytes = (long long)B * H * W * Cin;
+  p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act;
+  p.k_tap_fast = (ksize == 3 && Cin >= 512) ? 1 : 0;
+  return launch_gemm(MODE_FP8, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
 int dptx_op_conv_groupnorm(int32_t dtype, const void* X, const void* Wt, void* Yraw, const float* gamma, const float* beta,

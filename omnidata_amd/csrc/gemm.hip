@@ -54,7 +54,42 @@ template <int DT, int TM, int TN, bool RELU_A, int PL = 1, int HK = BK / 16>
 __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_lo, int b_lo, int wm, int wn, int lr, int lh,
                                          f32x16_t (&acc)[TM][TN]) {
   // a_lo / b_lo: byte distance of the lo-plane tiles inside the stage (PL == 2)
-  if constexpr (PL == 1) {
+  if constexpr (DT == DT_FP8) {
+    // a row of the k-tile is 128 e4m3 bytes.  v_mfma_scale_f32_32x32x64_f8f6f4 (format 0 = e4m3 for both operands, E8M0
+    // scale 127 = 1.0 in every byte of the scale registers: a plain fp8 MFMA at twice the bf16 rate) contracts 64 k per
+    // instruction; lane (lr, lh) supplies 32 consecutive bytes of its row -- the two 16-B chunks 4q + 2lh, 4q + 2lh + 1
+    // of MFMA q = 0, 1.  A and W use the same byte -> k assignment, so the contraction over the 128 bytes is complete
+    // whatever k order the instruction uses internally.
+    static_assert(PL == 1 && !RELU_A, "fp8: single plane; the producer writes the ReLU'd copy");
+    typedef int i32x8_t __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      i32x8_t af[TM], bf[TN];
+      const int c0 = 4 * q + 2 * lh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + lr;
+        const int sw = (row >> 1) & 7;
+        const u32x4_t lo = *(const u32x4_t*)(sa + row * 128 + ((c0 ^ sw) << 4));
+        const u32x4_t hi = *(const u32x4_t*)(sa + row * 128 + (((c0 + 1) ^ sw) << 4));
+        af[i] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + lr;
+        const int sw = (row >> 1) & 7;
+        const u32x4_t lo = *(const u32x4_t*)(sb + row * 128 + ((c0 ^ sw) << 4));
+        const u32x4_t hi = *(const u32x4_t*)(sb + row * 128 + (((c0 + 1) ^ sw) << 4));
+        bf[j] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+    return;
+  } else if constexpr (PL == 1) {
     // all fragment reads of the k-tile are issued up front (16 ds_read_b128 in flight for a 64x64 wave tile,
     // 64 VGPRs) and the MFMAs consume them behind counted lgkmcnt waits: the LDS latency is paid once per
     // k-tile instead of once per k-step
@@ -91,7 +126,7 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
       if (HK != BK / 16) __builtin_amdgcn_sched_barrier(0);
     }
     return;
-  }
+  } else {
 #pragma unroll
   for (int ks = 0; ks < BK / 16; ++ks) {
     const int chunk = 2 * ks + lh;
@@ -125,6 +160,7 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
         }
         acc[i][j] = T16<DT>::mfma32(af[i], bf[j], acc[i][j]);
       }
+  }
   }
 }
 
@@ -284,6 +320,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
             v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
           }
+          if (p.out_scale != 0.f) {  // fp8 GEMMs: the weights were scaled by a power of two before quantisation
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+          }
           if (bpi) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(bb[it][0][e]); v[4 + e] += __uint_as_float(bb[it][1][e]); }
@@ -328,6 +368,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             } else {
               store8f<DT, PL>((uint16_t*)p.C + coff[it], p.planes.act, v);
             }
+            if (p.C8 != nullptr) {  // e4m3 copy for an fp8 consumer (ReLU'd first when every consumer pre-activates)
+              if (p.q_relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+              }
+              *(uint2*)((uint8_t*)p.C8 + coff[it]) = pack_fp8x8(v);
+            }
           }
         }
       }
@@ -360,6 +407,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
   constexpr int PASS_BYTES = ROWS_PP * 128;
   constexpr int A_PASSES = BM / ROWS_PP, B_PASSES = BN / ROWS_PP;
   constexpr int HK = (TM * TN > 4) ? 2 : BK / 16;
+  constexpr int ES = DT == DT_FP8 ? 1 : 2;   // bytes per A / W element
+  constexpr int KE = 128 / ES;               // elements of K per k-tile (a tile row is 128 bytes)
+  constexpr int DTS = DT == DT_FP8 ? DT_BF16 : DT;  // type of C / residuals
   constexpr int SLABS = (BM * (BN + 4) * 4 > 160 * 1024) ? TM : 1;
   // stage image: [A hi][A lo (PL==2)][W hi][W lo (PL==2)]
   constexpr int A_LO = BM * 128, B_BASE = PL * BM * 128, B_LO = BN * 128;
@@ -404,14 +454,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
     a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;  // rows >= M never pass the bounds test
     a_ix0[i] = ox * p.stride - p.pad_l;
     const long long e = (long long)img * p.a_img_stride + p.a_off +
-                        ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * 8;
-    a_off[i] = (unsigned)(ok ? e * 2 : 0);
+                        ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * (16 / ES);
+    a_off[i] = (unsigned)(ok ? e * ES : 0);
   }
   unsigned w_off[B_PASSES];
 #pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + ROWS_PP * j) * p.ldw + sc * 8) * 2);
+  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + ROWS_PP * j) * p.ldw + sc * (16 / ES)) * ES);
 
-  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
+  const int w_bytes = (int)((long long)p.N * p.ldw * ES);
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
   // lo planes (bf16x3 mode): same offsets, bases shifted by the plane distance
@@ -426,8 +476,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
   do {                                                                                                             \
     char* sa_ = smem + (BUF) * STAGE_BYTES + wave * 1024;                                                          \
     char* sb_ = sa_ + B_BASE;                                                                                      \
-    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
-    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);  /* k = (tap, channel) in W */           \
+    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * ES);                              \
+    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * ES);  /* k = (tap, channel) in W */          \
     _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                         \
       const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
       const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
@@ -448,10 +498,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
     if (p.k_tap_fast) { /* the nine taps re-read the same input lines in nine consecutive k-tiles (L2-resident) */ \
       if (++kx == p.ksz) {                                                                                         \
         kx = 0;                                                                                                    \
-        if (++ky == p.ksz) { ky = 0; c0 += BK; }                                                                   \
+        if (++ky == p.ksz) { ky = 0; c0 += KE; }                                                                   \
       }                                                                                                            \
     } else { /* channels-fastest inside a tap */                                                                   \
-      c0 += BK;                                                                                                    \
+      c0 += KE;                                                                                                    \
       if (c0 >= p.Cin) {                                                                                           \
         c0 = 0;                                                                                                    \
         if (++kx == p.ksz) { kx = 0; ++ky; }                                                                       \
@@ -467,7 +517,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK;
+  const int nk = p.K / KE;
   DPTX_ISSUE_TILE(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed (every wave waits for its own DMA, then the barrier publishes all of
@@ -480,7 +530,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
   }
 #undef DPTX_ISSUE_TILE
   __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
-  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+  epilogue<DTS, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
 }
 
@@ -684,6 +734,14 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
                        p.M < (1 << 23);
   if (PL == 2 && !glds_ok) return hipErrorInvalidValue;  // the 3-pass mode exists only on the direct-to-LDS path
+  if constexpr (DT == DT_FP8) {  // fp8 operands: direct-to-LDS path only, pre-activation is the producer's job
+    if (!glds_ok || p.a_relu) return hipErrorInvalidValue;
+    auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
+    static bool done = false;
+    if (!done) { set_smem_attr(k, smem); done = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
+    return hipGetLastError();
+  } else
   if (glds_ok && (PL == 2 || gemm_variant() != 1)) {
     if (p.a_relu) {
       auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL>;
@@ -772,6 +830,11 @@ hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
   if (p.gn_part != nullptr && (p.gn_hw % 32 != 0 || p.N % 32 != 0 || p.gn_cpg != p.N / 32 || p.gn_cpg < 2 || p.gn_cpg > 32 ||
                                (p.gn_cpg & (p.gn_cpg - 1)) != 0 || p.bias != nullptr || p.act != 0))
     return hipErrorInvalidValue;  // statistics are those of the raw accumulators: no bias / activation in front of a GroupNorm
+  if (mode == MODE_FP8) {  // 128 e4m3 per k-tile row
+    if (p.K % 128 != 0 || p.Cin % 128 != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 16 != 0 || p.gn_part != nullptr)
+      return hipErrorInvalidValue;
+    return launch_dt<DT_FP8, 1>(p, stream);
+  }
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 8 != 0) return hipErrorInvalidValue;
   if (mode == MODE_BF16) return launch_dt<DT_BF16, 1>(p, stream);
   if (mode == MODE_FP16) return launch_dt<DT_FP16, 1>(p, stream);

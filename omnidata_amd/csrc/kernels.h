@@ -41,6 +41,12 @@ struct GemmParams {
   // of (sum, sum of squares) per 32-row block; gn_hw = rows per image (% 32 == 0), gn_cpg = N / 32 channels per group
   float* gn_part;
   int gn_hw, gn_blocks, gn_cpg;
+  // fp8 (MODE_FP8: A and W are e4m3 bytes, K and ldw count bytes): C *= out_scale before the bias (0 = none); C8: optional
+  // e4m3 copy of the final output (same addressing as C, 1 byte per element), ReLU'd first when q_relu -- also available
+  // to the 16-bit modes (the producers of an fp8 GEMM's input run in bf16)
+  void* C8;
+  int q_relu;
+  float out_scale;
   float a_rpi_rcp, wout_rcp;  // 1 / a_rpi, 1 / Wout (filled in by launch_gemm: row -> (image, y, x) without integer division)
 };
 
@@ -80,7 +86,9 @@ hipError_t launch_stem_conv(int mode, const void* x, int io, const void* Wt, voi
                             hipStream_t stream);
 
 // bilinear x2 align_corners=True on NHWC 16-bit
-hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream);
+// Y8 (optional): e4m3 copy of the output, 1 byte per element, for an fp8 convolution downstream
+hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream,
+                             void* Y8 = nullptr);
 
 // y NCHW fp32 [B,Cout,HW] = act( W[Cout][32] * x[B*HW,32] + b ),  Cout <= 4
 hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, void* y, int io, int B, int HW,

@@ -14,8 +14,9 @@ namespace dptx {
 // block), a thread owns 8 channels of one output pixel; C/8 is a power of two on every call site, so the
 // per-thread index math is shifts and masks.
 template <int DT, int PL>
-__global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y, int B, int H,
-                                                         int W, int C, int cshift, long long plane) {
+__global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y,
+                                                         uint8_t* __restrict__ Y8, int B, int H, int W, int C, int cshift,
+                                                         long long plane) {
   const int Ho = 2 * H, Wo = 2 * W, cvec = C >> 3;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Wo * cvec) return;
@@ -37,16 +38,18 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restr
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = bilerp(a[e], bb[e], c[e], d[e], lx0, lx1, ly0, ly1);
   store8f<DT, PL>(Y + ((long long)blockIdx.y * Wo + ox) * C + v * 8, plane, o);
+  if (Y8 != nullptr) *(uint2*)(Y8 + ((long long)blockIdx.y * Wo + ox) * C + v * 8) = pack_fp8x8(o);  // e4m3 copy for an fp8 conv
 }
 
-hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream) {
+hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream,
+                             void* Y8) {
   const int cvec = C / 8;
   if (C % 8 != 0 || (cvec & (cvec - 1)) != 0 || (long long)H * W * C >= (1ll << 31)) return hipErrorInvalidValue;
   int cshift = 0;
   while ((1 << cshift) < cvec) ++cshift;
   dim3 grid((2 * W * cvec + 255) / 256, B * 2 * H);
   DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((upsample2x_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X,
-                                              (uint16_t*)Y, B, H, W, C, cshift, pl.act));
+                                              (uint16_t*)Y, (uint8_t*)Y8, B, H, W, C, cshift, pl.act));
   return hipGetLastError();
 }
 

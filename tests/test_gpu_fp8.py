@@ -1,0 +1,105 @@
+"""fp8 dtype (BASELINE.json configs[4] "fp8 MFMA weights"): the decoder's RCU / out_conv / first head convolutions on OCP
+e4m3 operands.  e4m3 has a 4-bit significand: every operand carries ~2^-4 relative rounding noise, so this is a throughput
+mode with ITS OWN stated tolerance, not a parity mode:
+
+  * op level (this file): the fp8 convolution against an fp32 convolution of the SAME e4m3 operands -- the kernel's own
+    arithmetic is exact up to fp32 accumulation, so the bf16-output tolerance of the 16-bit kernels applies (6e-3 of
+    max|ref|); its e4m3 output copy within one e4m3 ulp.
+  * end to end: against the fp32 CPU oracle on the seeded weights, mean angular error < 20 deg / rms < 6e-2 for the
+    normal head (CPU emulation of exactly this policy, oracle/precision_policy.py: 13.7 deg / 3.9e-2; bf16 alone is
+    3.6 deg / 1.1e-2), and the decoder stage taps grow by a few % rms per fp8 conv, not more.
+pytest -m gpu."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from omnidata_amd.engine import load_library
+from omnidata_amd.model import DPTDepthModel, DPTDualTaskModel
+from omnidata_amd.weights import random_dual_state_dict, synthetic_input
+from tests.gpu_util import OUT_TOL, ptr, rel_err, stream
+from tests.test_gpu_e2e import oracle_case
+from tests.test_gpu_ops import conv_ref
+from oracle.dpt_oracle import dpt_forward_dual, mean_angular_error_deg, oracle_threads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F8 = torch.float8_e4m3fn
+
+
+def r8(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(F8).to(DEV)
+
+
+# B, H, Cin, Cout, k, stride, pad, Ho, act, residual, q_relu
+@pytest.mark.parametrize("case", [(2, 24, 256, 256, 3, 1, 1, 24, 1, False, 0),    # RCU conv1 (ReLU epilogue)
+                                  (2, 24, 256, 256, 3, 1, 1, 24, 0, True, 1),     # RCU conv2 (+ residual), ReLU'd e4m3 copy
+                                  (3, 48, 256, 256, 1, 1, 0, 48, 0, False, 0),    # out_conv 1x1
+                                  (2, 48, 256, 128, 3, 1, 1, 48, 0, False, 0),    # first head conv (N = 128)
+                                  (8, 96, 256, 256, 3, 1, 1, 96, 0, True, 0),     # big M: 256x256 8-wave tile
+                                  (1, 12, 512, 64, 3, 1, 1, 12, 0, False, 1)])    # small map, N = 64, K = 4608
+def test_fp8_conv(case):
+    lib = load_library()
+    B, H, Cin, Cout, k, stride, pad, Ho, act, res, q_relu = case
+    X8 = r8(B, H, H, Cin, seed=30)
+    W8 = r8(Cout, k, k, Cin, scale=16.0, seed=31)          # weights as the engine stores them: scaled up to the e4m3 range
+    out_scale = (1.0 / 16.0) * (k * k * Cin) ** -0.5
+    bias = torch.randn(Cout, device=DEV) * 0.1
+    R = (torch.randn(B, Ho, Ho, Cout, generator=torch.Generator().manual_seed(32))).to(torch.bfloat16).to(DEV) if res else None
+    Y = torch.empty(B, Ho, Ho, Cout, device=DEV, dtype=torch.bfloat16)
+    Y8 = torch.zeros(B, Ho, Ho, Cout, device=DEV, dtype=torch.uint8)
+    rc = lib.dptx_op_conv_fp8(ptr(X8), ptr(W8), ptr(bias), ptr(R), ptr(Y), ptr(Y8), B, H, H, Cin, Cout, k, stride, pad, pad, Ho, Ho,
+                              act, q_relu, out_scale, stream())
+    assert rc == 0
+    ref = conv_ref(X8.float(), W8.float(), None, stride, pad, pad, Ho, Ho, 0) * out_scale + bias
+    if act == 1:
+        ref = F.relu(ref)
+    if res:
+        ref = ref + R.float()
+    assert rel_err(Y.float(), ref) < OUT_TOL["bf16"]
+    want8 = (F.relu(ref) if q_relu else ref).clamp(-448, 448)
+    got8 = Y8.view(F8).float()
+    # the copy is the e4m3 rounding of the kernel's fp32 value: it can differ from the rounding of `ref` by one e4m3 step
+    # where the two fp32 values straddle a rounding boundary
+    step = torch.exp2(torch.floor(torch.log2(want8.abs().clamp_min(2.0 ** -6))) - 3)
+    assert ((got8 - want8).abs() <= step * 1.001 + 1e-6).all()
+    assert float((got8 == want8.to(F8).float()).float().mean()) > 0.98
+
+
+def test_fp8_end_to_end_stated_tolerance():
+    sd, x, ref, otaps = oracle_case("normal", 3, 0, 1)
+    model = DPTDepthModel(num_channels=3, dtype="fp8", max_batch=1)
+    model.load_state_dict(sd)
+    model.to(DEV)
+    eng = model._get_engine(torch.device(DEV))
+    eng.enable_taps(True)
+    y = model(x.to(DEV)).cpu()
+    d = (y - ref).abs()
+    ang = mean_angular_error_deg(y.clamp(0, 1), ref.clamp(0, 1))
+    print(f"\n[fp8 decoder, bf16 elsewhere] max|d|={d.max():.3e} rms={d.pow(2).mean().sqrt():.3e} mean angular error {ang:.2f} deg")
+    rel = {}
+    for n in ["s2", "blk11", "l1_rn", "l4_rn", "p4", "p3", "p2", "p1", "h0"]:
+        got, want = eng.tap(n), otaps[n]
+        rel[n] = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+        print(f"    tap {n:6s} rms-rel err {rel[n]:.3e}")
+    assert torch.isfinite(y).all() and (y >= 0).all()
+    assert ang < 20.0 and d.pow(2).mean().sqrt() < 6e-2
+    assert rel["l1_rn"] < 0.2 and max(rel[n] for n in ("p4", "p3", "p2", "p1", "h0")) < 0.35
+
+
+def test_fp8_dual_task_runs_and_is_deterministic():
+    sd = random_dual_state_dict(3)
+    x = synthetic_input(11, 3, "normal")
+    dual = DPTDualTaskModel(dtype="fp8", max_batch=3)
+    dual.load_state_dict(sd)
+    dual.to(DEV)
+    yn, yd = dual(x.to(DEV))
+    assert yn.shape == (3, 3, 384, 384) and yd.shape == (3, 384, 384)
+    yn2, yd2 = dual(x.to(DEV))
+    assert torch.equal(yn, yn2) and torch.equal(yd, yd2)
+    oracle_threads()
+    rn, rd = dpt_forward_dual(sd, x)
+    en, ed = (yn.cpu() - rn), (yd.cpu() - rd)
+    print(f"\n[fp8 dual] normal rms {en.pow(2).mean().sqrt():.3e} ang {mean_angular_error_deg(yn.cpu().clamp(0, 1), rn.clamp(0, 1)):.2f} deg; "
+          f"depth rms {ed.pow(2).mean().sqrt():.3e}")
+    assert en.pow(2).mean().sqrt() < 6e-2 and ed.pow(2).mean().sqrt() < 6e-2

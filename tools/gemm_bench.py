@@ -54,14 +54,15 @@ def main():
     ITERS[0] = args.iters
     build()
     lib = load_library()
-    dt, tdt = DTYPES[args.dtype], (torch.bfloat16 if args.dtype == "bf16" else torch.float16)
+    fp8 = args.dtype == "fp8"
+    dt, tdt = DTYPES[args.dtype], (torch.bfloat16 if args.dtype in ("bf16", "fp8") else torch.float16)
     st = torch.cuda.current_stream().cuda_stream
     print(f"variant={os.environ.get('DPTX_GEMM', 'glds')} dtype={args.dtype}")
     tot_ms, tot_flop = 0.0, 0.0
     # the ViT GEMMs run with the epilogue the engine gives them: fc1 bias + GELU; proj / fc2 bias + in-place fp32 residual
     EPI = {"vit.fc1": (2, False), "vit.proj": (0, True), "vit.fc2": (0, True)}
     for name, M, N, K in DENSE:
-        if only and name not in only:
+        if (only and name not in only) or fp8:
             continue
         act, inplace32 = EPI.get(name, (0, False))
         A = torch.randn(M, K, device="cuda").to(tdt)
@@ -77,12 +78,19 @@ def main():
     for name, H, Cin, Cout, k, s, pad, Ho in CONV:
         if only and name not in only:
             continue
-        X = torch.randn(B, H, H, Cin, device="cuda").to(tdt)
-        Wt = (torch.randn(Cout, k, k, Cin, device="cuda") * (k * k * Cin) ** -0.5).to(tdt)
+        if fp8 and Cin % 128:
+            continue
+        X = torch.randn(B, H, H, Cin, device="cuda").to(torch.float8_e4m3fn if fp8 else tdt)
+        Wt = (torch.randn(Cout, k, k, Cin, device="cuda") * (16.0 if fp8 else (k * k * Cin) ** -0.5)).to(torch.float8_e4m3fn if fp8 else tdt)
         Y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=tdt)
         bias = torch.randn(Cout, device="cuda")
-        ms = timeit(lambda: lib.dptx_op_conv(dt, X.data_ptr(), Wt.data_ptr(), bias.data_ptr(), None, Y.data_ptr(), B, H, H, Cin, Cout, k, s,
-                                             pad, pad, Ho, Ho, 0, 0, st))
+        if fp8:  # the fp8 dtype's convolution: e4m3 operands, bf16 output + e4m3 copy of it
+            Y8 = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=torch.uint8)
+            ms = timeit(lambda: lib.dptx_op_conv_fp8(X.data_ptr(), Wt.data_ptr(), bias.data_ptr(), None, Y.data_ptr(), Y8.data_ptr(), B, H,
+                                                     H, Cin, Cout, k, s, pad, pad, Ho, Ho, 0, 0, 1.0 / 768, st))
+        else:
+            ms = timeit(lambda: lib.dptx_op_conv(dt, X.data_ptr(), Wt.data_ptr(), bias.data_ptr(), None, Y.data_ptr(), B, H, H, Cin, Cout,
+                                                 k, s, pad, pad, Ho, Ho, 0, 0, st))
         M, K = B * Ho * Ho, k * k * Cin
         fl = 2.0 * M * Cout * K
         print(f"{name:14s} M={M:8d} N={Cout:5d} K={K:5d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s")
