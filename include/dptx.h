@@ -238,6 +238,9 @@ int dptx_op_layernorm(int32_t dtype, const float* x, const float* gamma, const f
 int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const float* beta,
                       const void* R, void* Y, int32_t B, int32_t HW, int32_t C, int32_t relu,
                       float eps, void* scratch_f32, void* stream);
+/* Debug: s_memtime stamps of the GEMM k-loop (block 0, lane 0 of each wave; [wave][64 k-tiles][4 phases] int64) into a
+ * device buffer of 8*64*4 int64 for every following GEMM launch; NULL switches it off (tools/gpu/gemm_trace.py). */
+int dptx_debug_set_trace(void* dev_buf);
 /* NHWC conv on OCP e4m3 operands (the fp8 dtype's convolution): X8[B,H,W,Cin] and Wt8[Cout][k][k][Cin] are e4m3 bytes
  * (Cin % 128 == 0), fp32 accumulate on the block-scaled fp8 MFMA at unit scale; Y = act(out_scale * conv + bias) (+R) in
  * bf16; Y8 (optional) receives the e4m3 copy of Y (ReLU'd first when q_relu). */

@@ -23,8 +23,13 @@ def _newer(dst: str, srcs) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """DPTX_CXXFLAGS / DPTX_LIB_SUFFIX (experiments): extra compiler flags and a suffix for the object directory and the
+    library name (libdptx<suffix>.so), so that kernel variants can be built side by side; engine.py loads $DPTX_LIB."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(CSRC, "build")
+    extra = os.environ.get("DPTX_CXXFLAGS", "").split()
+    suffix = os.environ.get("DPTX_LIB_SUFFIX", "")
+    LIB = os.path.join(HERE, f"libdptx{suffix}.so")
+    objdir = os.path.join(CSRC, "build" + suffix)
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
@@ -35,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if not force and _newer(o, [s] + hdrs):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -320,10 +320,12 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
             v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
           }
+#ifndef DPTX_NO_F8EPI   // A/B builds: what do the fp8 hooks cost the 16-bit kernels?
           if (p.out_scale != 0.f) {  // fp8 GEMMs: the weights were scaled by a power of two before quantisation
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
           }
+#endif
           if (bpi) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(bb[it][0][e]); v[4 + e] += __uint_as_float(bb[it][1][e]); }
@@ -368,6 +370,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             } else {
               store8f<DT, PL>((uint16_t*)p.C + coff[it], p.planes.act, v);
             }
+#ifndef DPTX_NO_F8EPI
             if (p.C8 != nullptr) {  // e4m3 copy for an fp8 consumer (ReLU'd first when every consumer pre-activates)
               if (p.q_relu) {
 #pragma unroll
@@ -375,6 +378,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
               }
               *(uint2*)((uint8_t*)p.C8 + coff[it]) = pack_fp8x8(v);
             }
+#endif
           }
         }
       }
@@ -518,19 +522,198 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / KE;
+  // debug trace (p.trace): per k-tile, lane 0 of every wave of block 0 stamps s_memtime after the barrier, after the DMA
+  // issue, after the MFMAs and after the wait for the next tile: where does an iteration's time go?
+  const bool tr = p.trace != nullptr && blockIdx.x == 0 && lane == 0;
+  long long* trp = p.trace + wave * 4 * 64;
+#ifdef DPTX_TRACE   // experiment builds only (build.py DPTX_CXXFLAGS=-DDPTX_TRACE): the stamps cost registers and issue slots
+#define DPTX_STAMP(SLOT) do { if (tr && kt < 64) trp[kt * 4 + (SLOT)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DPTX_STAMP(SLOT) do { } while (0)
+#endif
+#ifdef DPTX_TRACE
+  if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
+#endif
   DPTX_ISSUE_TILE(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed (every wave waits for its own DMA, then the barrier publishes all of
     // them) and every wave is done reading the other stage, which the next DMA overwrites
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DPTX_STAMP(3);
     __syncthreads();
-    if (kt + 1 < nk) DPTX_ISSUE_TILE((kt + 1) & 1, (kt + 1) * BK);
+    DPTX_STAMP(0);
     const char* sa = smem + (kt & 1) * STAGE_BYTES;
+    if (kt + 1 < nk) DPTX_ISSUE_TILE((kt + 1) & 1, (kt + 1) * BK);
+    DPTX_STAMP(1);
     mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, A_LO, B_LO, wm, wn, lr, lh, acc);
+    DPTX_STAMP(2);
   }
+#ifdef DPTX_TRACE
+  if (tr && wave == 0) { trp[62 * 4 + 2] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 3] = (long long)wall_clock64(); }
+#endif
+#undef DPTX_STAMP
 #undef DPTX_ISSUE_TILE
   __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
   epilogue<DTS, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+#endif
+}
+
+// ------------------------------------------------------------------- ping-pong 256x256 kernel
+// The k-loop trace of gemm_glds_kernel (tools/gpu/gemm_trace.py, profiles/r02_gemm_trace.txt) shows what bounds the
+// 256x256 tile: an iteration is 4100 cycles for 2048 cycles of MFMA work per SIMD, because the eight waves run in
+// lockstep -- they all issue their 8 LDS-DMA instructions first (~100-170 cycles EACH, during which a wave issues nothing
+// else: 850-1400 cycles with the matrix pipe idle), then all read fragments, then the two waves of every SIMD queue their
+// MFMAs behind each other.  The DMA latency itself is hidden (the wait for the next tile is ~300 cycles).
+//
+// Here the two wave groups (wm = 0 / 1: the upper / lower 128 rows of the tile, one wave of each on every SIMD) run the
+// SAME work half an iteration apart, two barriers per k-tile:
+//     slot 1:  group 0 issues DMA for tile t+1          |  group 1 multiplies tile t
+//     slot 2:  group 0 multiplies tile t                |  group 1 issues DMA for tile t+1
+// so a SIMD always has one wave feeding the matrix pipe while the other is stuck in the DMA issue.  Who loads what follows
+// from who needs it first: group 1 multiplies tile t+1 in the very next slot after group 1's own issue slot, so everything
+// group 1 reads -- A rows 128..255 and all of W -- is issued by GROUP 0 one full slot earlier (12 instructions per wave),
+// and group 1 issues only A rows 0..127 (4 instructions), which group 0 reads a full iteration later.  Every wave drains
+// its own DMA (vmcnt(0)) at the end of its MFMA slot, i.e. before the barrier in front of the first reader.
+template <int DT, bool RELU_A>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, HK = 2, PL = 1;
+  constexpr int SLABS = TM;
+  constexpr int B_BASE = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // group = wm
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
+    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
+    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
+    if (mt >= tiles_m || l >= tm_per * tn_per) return;
+    m0 = mt * BM;
+    n0 = nt * BN;
+  }
+
+  // loader of a group: thread (r0 = t>>3, kc = t&7), t = tid % 256, owns LDS chunk kc of rows base + r0 + 32*i.
+  // Group 0 loads A rows 128..255 (4 passes) and W rows 0..255 (8 passes); group 1 loads A rows 0..127 (4 passes).
+  const int t = tid & 255;
+  const int kc = t & 7, r0 = t >> 3;
+  const int sc = kc ^ ((r0 >> 1) & 7);
+  const int a_row0 = wm == 0 ? 128 : 0;
+  int a_iy0[4], a_ix0[4];
+  unsigned a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + a_row0 + r0 + 32 * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    int rem, ox;
+    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
+    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
+    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
+    a_ix0[i] = ox * p.stride - p.pad_l;
+    const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * 8;
+    a_off[i] = (unsigned)(ok ? e * 2 : 0);
+  }
+  unsigned w_off[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2);
+  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
+
+  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k-tile this group loads next (wave-uniform)
+  const int wq = wave & 3;     // wave inside its group: rows 8*wq .. 8*wq+7 of every 32-row pass
+#define DPTX_PP_ISSUE(BUF)                                                                                         \
+  do {                                                                                                             \
+    char* st_ = smem + (BUF) * STAGE_BYTES;                                                                        \
+    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
+      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                    \
+          rsrcA, (__attribute__((address_space(3))) void*)(st_ + (a_row0 + 32 * i) * 128 + wq * 1024), 16,          \
+          valid ? a_off[i] + tap_ : OOB, 0, 0, 0);                                                                 \
+    }                                                                                                              \
+    if (wm == 0) {                                                                                                 \
+      const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);                                     \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
+            rsrcW, (__attribute__((address_space(3))) void*)(st_ + B_BASE + 32 * j * 128 + wq * 1024), 16,          \
+            w_off[j] + wk_, 0, 0, 0);                                                                              \
+    }                                                                                                              \
+    if (p.k_tap_fast) {                                                                                            \
+      if (++kx == p.ksz) { kx = 0; if (++ky == p.ksz) { ky = 0; c0 += BK; } }                                      \
+    } else {                                                                                                       \
+      c0 += BK;                                                                                                    \
+      if (c0 >= p.Cin) { c0 = 0; if (++kx == p.ksz) { kx = 0; ++ky; } }                                            \
+    }                                                                                                              \
+  } while (0)
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  const bool tr = p.trace != nullptr && blockIdx.x == 0 && lane == 0;
+  long long* trp = p.trace + wave * 4 * 64;
+#ifdef DPTX_TRACE   // experiment builds only (build.py DPTX_CXXFLAGS=-DDPTX_TRACE): the stamps cost registers and issue slots
+#define DPTX_STAMP(SLOT) do { if (tr && kt < 64) trp[kt * 4 + (SLOT)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DPTX_STAMP(SLOT) do { } while (0)
+#endif
+#ifdef DPTX_TRACE
+  if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
+#endif
+  DPTX_PP_ISSUE(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
+  // that hipcc resolves with copies: 500 spilled registers)
+  if (wm == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      DPTX_STAMP(0);
+      if (kt + 1 < nk) DPTX_PP_ISSUE((kt + 1) & 1);              // slot 1
+      DPTX_STAMP(1);
+      asm volatile("s_barrier" ::: "memory");
+      DPTX_STAMP(2);
+      const char* sa = smem + (kt & 1) * STAGE_BYTES;            // slot 2
+      mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, 0, 0, 0, wn, lr, lh, acc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of slot 1 has landed before group 1 reads it
+      DPTX_STAMP(3);
+      asm volatile("s_barrier" ::: "memory");
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      DPTX_STAMP(0);
+      const char* sa = smem + (kt & 1) * STAGE_BYTES;            // slot 1
+      mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, 0, 0, 1, wn, lr, lh, acc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of the previous slot 2 (A rows 0..127 of THIS
+      DPTX_STAMP(1);                                             // tile) has landed before group 0 reads it in slot 2
+      asm volatile("s_barrier" ::: "memory");
+      DPTX_STAMP(2);
+      if (kt + 1 < nk) DPTX_PP_ISSUE((kt + 1) & 1);              // slot 2
+      DPTX_STAMP(3);
+      asm volatile("s_barrier" ::: "memory");
+    }
+  }
+#ifdef DPTX_TRACE
+  if (tr && wave == 0) { trp[62 * 4 + 2] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 3] = (long long)wall_clock64(); }
+#endif
+#undef DPTX_STAMP
+#undef DPTX_PP_ISSUE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
 }
 
@@ -734,6 +917,24 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
                        p.M < (1 << 23);
   if (PL == 2 && !glds_ok) return hipErrorInvalidValue;  // the 3-pass mode exists only on the direct-to-LDS path
+  if constexpr (DT != DT_FP8 && PL == 1 && BM == 256 && BN == 256) {
+    static int pp = -1;  // ping-pong schedule of the two wave groups (gemm_pp_kernel); DPTX_PP=0: the lockstep loop (A/B runs)
+    if (pp < 0) { const char* t = getenv("DPTX_PP"); pp = t ? atoi(t) : 1; }
+    if (pp && glds_ok) {
+      if (p.a_relu) {
+        auto k = gemm_pp_kernel<DT, true>;
+        static bool done = false;
+        if (!done) { set_smem_attr(k, smem); done = true; }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
+      } else {
+        auto k = gemm_pp_kernel<DT, false>;
+        static bool done = false;
+        if (!done) { set_smem_attr(k, smem); done = true; }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
+      }
+      return hipGetLastError();
+    }
+  }
   if constexpr (DT == DT_FP8) {  // fp8 operands: direct-to-LDS path only, pre-activation is the producer's job
     if (!glds_ok || p.a_relu) return hipErrorInvalidValue;
     auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
@@ -784,17 +985,21 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
     if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
     if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
   }
-  // 256x256 (8 waves, 1 block/CU): half the DMA issues and 3/4 of the LDS reads per MFMA of the 128x128 tile, but no
-  // second block to hide prologue/epilogue and a coarser tail.  Measured (profiles/r01_gemm_tile256_ab.txt): +3..8 %
-  // on long-K problems whose tile count fills the 256 CUs evenly (fc2, the 3x3 convs at 1/4 resolution), -2..-22 %
-  // elsewhere -- so: K >= 2048 and >= 85 % of the last round of CUs busy.
+  // 256x256 (8 waves, 1 block/CU; 16-bit modes: the ping-pong kernel): half the DMA issues and 3/4 of the LDS reads per MFMA
+  // of the 128x128 tile, but no second block to hide prologue/epilogue and a coarser tail.  Chosen when its estimated
+  // efficiency wins: fill of the last round of CUs (256 slots) x 1.07 (the measured per-tile advantage at K >= 512,
+  // profiles/r02_experiments.md) against the fill of the 128x128 grid (512 slots).  That picks it for fc2, qkv, proj,
+  // patch-embed and the 3x3 convs at 1/4 resolution and keeps 128x128 for fc1 (85.6 % vs 97 % fill) and the small maps.
   if constexpr (PL == 1) {
     const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
     static int min_k = -1;  // DPTX_T256_MINK: shortest K that takes the 256x256 tile (experiments)
-    if (min_k < 0) { const char* t = getenv("DPTX_T256_MINK"); min_k = t ? atoi(t) : 2048; }
-    const long long t256 = m256 * (p.N / 256), rounds = (t256 + 255) / 256;
-    if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= min_k && t256 >= 200 && t256 * 100 >= rounds * 256 * 85)
-      return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
+    if (min_k < 0) { const char* t = getenv("DPTX_T256_MINK"); min_k = t ? atoi(t) : 512; }
+    if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= min_k) {
+      const long long t256 = m256 * (p.N / 256), r256 = (t256 + 255) / 256;
+      const long long t128 = m128 * (p.N / 128), r128 = (t128 + 511) / 512;
+      const double fill256 = (double)t256 / (double)(r256 * 256), fill128 = (double)t128 / (double)(r128 * 512);
+      if (t256 >= 200 && fill256 * 1.07 >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
+    }
   }
   if constexpr (PL == 2) {
     // 3-MFMA modes are one block per CU (two planes of two stages = 128 KB of LDS); eight waves (2 x 4, wave tile
@@ -823,8 +1028,12 @@ void gemm_params_dense(GemmParams& p, int M, int N, int K) {
   p.a_bytes = (long long)M * K * 2;
 }
 
+static long long* g_trace = nullptr;
+void gemm_set_trace(long long* dev_buf) { g_trace = dev_buf; }
+
 hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
+  p.trace = g_trace;
   p.a_rpi_rcp = 1.0f / (float)(p.a_rpi > 0 ? p.a_rpi : 1);
   p.wout_rcp = 1.0f / (float)(p.Wout > 0 ? p.Wout : 1);
   if (p.gn_part != nullptr && (p.gn_hw % 32 != 0 || p.N % 32 != 0 || p.gn_cpg != p.N / 32 || p.gn_cpg < 2 || p.gn_cpg > 32 ||

@@ -47,6 +47,7 @@ struct GemmParams {
   void* C8;
   int q_relu;
   float out_scale;
+  long long* trace;  // debug: s_memtime stamps of block 0 (dptx_debug_set_trace); null in production
   float a_rpi_rcp, wout_rcp;  // 1 / a_rpi, 1 / Wout (filled in by launch_gemm: row -> (image, y, x) without integer division)
 };
 
@@ -54,6 +55,9 @@ struct GemmParams {
 void gemm_params_dense(GemmParams& p, int M, int N, int K);
 // dtype 0 bf16 / 1 fp16.  Picks the tile configuration from (M, N).  Returns hipError_t.
 hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
+// debug: every following GEMM launch stamps s_memtime per k-tile phase for the 8 waves of block 0 into dev_buf
+// ([wave][64 k-tiles][4] int64; null switches it off)
+void gemm_set_trace(long long* dev_buf);
 
 hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, int heads, Planes pl, hipStream_t stream);
 

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdptx.so")
+LIB_PATH = os.environ.get("DPTX_LIB") or os.path.join(_HERE, "libdptx.so")  # $DPTX_LIB: an experiment build (build.py)
 
 DTYPES = {"bf16": 0, "fp16": 1, "bf16x3": 2, "fp16x3": 3, "mixed": 4, "fp8": 5}
 # layer groups of dptx_config.x3_groups (include/dptx.h DPTX_GROUP_*)
@@ -70,6 +70,7 @@ ABI = [
     ("dptx_op_attention", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_op_layernorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
     ("dptx_op_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp]),
+    ("dptx_debug_set_trace", C.c_int, [_vp]),
     ("dptx_op_conv_fp8", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [C.c_float, _vp]),
     ("dptx_op_conv_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 12 + [C.c_float, _vp, _vp]),
     ("dptx_op_upsample2x", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
