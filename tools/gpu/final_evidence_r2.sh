@@ -1,0 +1,37 @@
+#!/bin/bash
+# end-of-round evidence (round 2): full gpu suite, smoke, bench lines, rocprofv3 trace + PMC passes, summaries
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/final2
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --tb=short --timeout=900 > $O/pytest_gpu.log 2>&1; echo "exit $?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
+timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+timeout 900 python bench.py --steps 20 --warmup 5 --profile-dump $O/launches.csv > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-300
+for cfg in "--dtype mixed" "--dtype fp16x3" "--dtype fp16" "--task depth" "--task dual" "--task dual --dtype fp8" "--dtype fp8" "--io bf16"; do
+  n=$(echo $cfg | tr -d ' -' )
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $cfg > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$cfg', d['value'], d['ms_per_step'])"
+done
+DPTX_STREAMS=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_1stream.log 2>&1; tail -1 $O/bench_1stream.log | cut -c1-120
+timeout 600 python tools/precision_frontier.py --steps 10 --out $O/frontier.md > $O/frontier.log 2>&1; tail -3 $O/frontier.log
+cd /tmp
+export DPTX_STREAMS=1   # kernel-level passes: one launch per layer over the whole batch (the bench's per-launch figures)
+B="python $R/bench.py --no-cpu-baseline --profile-steps 1"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o r -- $B --steps 5 --warmup 2 > $O/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- $B --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o r -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS -d $O/pmc_sq -o r -- $B --steps 2 --warmup 1 > $O/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_misc -o r -- $B --steps 2 --warmup 1 > $O/pmc_misc.log 2>&1
+unset DPTX_STREAMS
+cd $R
+db() { find $O/$1 -name "*.db" | head -1; }
+python tools/rocprof_summary.py $(db trace) > $O/r02_kernel_trace_stats.txt 2>&1
+python tools/rocprof_summary.py $(db pmc_fetch) --pmc > $O/r02_pmc_fetch_size.txt 2>&1
+python tools/rocprof_summary.py $(db pmc_write) --pmc > $O/r02_pmc_write_size.txt 2>&1
+python tools/rocprof_summary.py $(db pmc_sq) --pmc > $O/r02_pmc_sq.txt 2>&1
+python tools/rocprof_summary.py $(db pmc_misc) --pmc > $O/r02_pmc_misc.txt 2>&1
+python tools/pmc_traffic.py $(db pmc_fetch) $(db pmc_write) 4 130 > $O/r02_pmc_traffic.json 2>&1
+cat $O/r02_pmc_traffic.json | head -12
+head -12 $O/r02_kernel_trace_stats.txt
+find $O -name "*.db" -size +20M -delete
+du -sh $O

@@ -7,7 +7,7 @@ import json
 import sqlite3
 import sys
 
-FAMILY = ("gemm_glds_kernel", "gemm_reg_kernel", "stem_conv_kernel", "head_tail_kernel")
+FAMILY = ("gemm_glds_kernel", "gemm_pp_kernel", "gemm_reg_kernel", "stem_conv_kernel", "head_tail_kernel")
 
 
 def total(db, counter):
