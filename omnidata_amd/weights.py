@@ -25,13 +25,90 @@ VIT_DEPTH, VIT_DIM, VIT_MLP = 12, 768, 3072
 FEATURES = 256
 
 
-def state_dict_spec(num_channels: int = 3, include_unused: bool = True) -> "OrderedDict[str, Tuple[int, ...]]":
+BACKBONES = ("vitb_rn50_384", "vitl16_384")
+
+
+def vitl16_state_dict_spec(num_channels: int = 1, include_unused: bool = True) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Ordered {key: shape} of ``DPTDepthModel(backbone='vitl16_384', num_channels=C)`` (DPT-Large: blocks.py:12-18,
+    vit.py:299-309 hooks [5,11,17,23], reassemble vit.py:176-260): timm ``vit_large_patch16_384`` under ``pretrained.model.``
+    (16x16 patch conv, 24 blocks of width 1024, 16 heads), four ProjectReadouts, ConvTranspose2d up-sampling in
+    act_postprocess1/2, and the same scratch / RefineNet / head modules with layerN_rn inputs [256, 512, 1024, 1024]."""
+    D, depth, mlp = 1024, 24, 4096
+    sp: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    vp = "pretrained.model."
+    sp[vp + "cls_token"] = (1, 1, D)
+    sp[vp + "pos_embed"] = (1, 577, D)
+    sp[vp + "patch_embed.proj.weight"] = (D, 3, 16, 16)
+    sp[vp + "patch_embed.proj.bias"] = (D,)
+    for l in range(depth):
+        p = f"{vp}blocks.{l}."
+        sp[p + "norm1.weight"] = (D,)
+        sp[p + "norm1.bias"] = (D,)
+        sp[p + "attn.qkv.weight"] = (3 * D, D)
+        sp[p + "attn.qkv.bias"] = (3 * D,)
+        sp[p + "attn.proj.weight"] = (D, D)
+        sp[p + "attn.proj.bias"] = (D,)
+        sp[p + "norm2.weight"] = (D,)
+        sp[p + "norm2.bias"] = (D,)
+        sp[p + "mlp.fc1.weight"] = (mlp, D)
+        sp[p + "mlp.fc1.bias"] = (mlp,)
+        sp[p + "mlp.fc2.weight"] = (D, mlp)
+        sp[p + "mlp.fc2.bias"] = (D,)
+    if include_unused:
+        sp[vp + "norm.weight"] = (D,)
+        sp[vp + "norm.bias"] = (D,)
+        sp[vp + "head.weight"] = (1000, D)
+        sp[vp + "head.bias"] = (1000,)
+    feats = (256, 512, 1024, 1024)
+    for n, f in enumerate(feats, start=1):
+        p = f"pretrained.act_postprocess{n}."
+        sp[p + "0.project.0.weight"] = (D, 2 * D)
+        sp[p + "0.project.0.bias"] = (D,)
+        sp[p + "3.weight"] = (f, D, 1, 1)
+        sp[p + "3.bias"] = (f,)
+        if n == 1:
+            sp[p + "4.weight"] = (f, f, 4, 4)   # ConvTranspose2d(k=4, s=4): [Cin, Cout, kh, kw]
+            sp[p + "4.bias"] = (f,)
+        elif n == 2:
+            sp[p + "4.weight"] = (f, f, 2, 2)   # ConvTranspose2d(k=2, s=2)
+            sp[p + "4.bias"] = (f,)
+        elif n == 4:
+            sp[p + "4.weight"] = (f, f, 3, 3)   # Conv2d(k=3, s=2, p=1)
+            sp[p + "4.bias"] = (f,)
+    for i, c in enumerate(feats, start=1):
+        sp[f"scratch.layer{i}_rn.weight"] = (FEATURES, c, 3, 3)
+    for i in (1, 2, 3, 4):
+        p = f"scratch.refinenet{i}."
+        sp[p + "out_conv.weight"] = (FEATURES, FEATURES, 1, 1)
+        sp[p + "out_conv.bias"] = (FEATURES,)
+        for u in (1, 2):
+            if u == 1 and i == 4 and not include_unused:
+                continue
+            for c in (1, 2):
+                sp[f"{p}resConfUnit{u}.conv{c}.weight"] = (FEATURES, FEATURES, 3, 3)
+                sp[f"{p}resConfUnit{u}.conv{c}.bias"] = (FEATURES,)
+    oc = "scratch.output_conv."
+    sp[oc + "0.weight"] = (FEATURES // 2, FEATURES, 3, 3)
+    sp[oc + "0.bias"] = (FEATURES // 2,)
+    sp[oc + "2.weight"] = (32, FEATURES // 2, 3, 3)
+    sp[oc + "2.bias"] = (32,)
+    sp[oc + "4.weight"] = (num_channels, 32, 1, 1)
+    sp[oc + "4.bias"] = (num_channels,)
+    return sp
+
+
+def state_dict_spec(num_channels: int = 3, include_unused: bool = True,
+                    backbone: str = "vitb_rn50_384") -> "OrderedDict[str, Tuple[int, ...]]":
     """Ordered {key: shape} of ``DPTDepthModel(backbone='vitb_rn50_384', num_channels=C)``.
 
     ``include_unused`` adds the tensors a real checkpoint carries but the forward never
     reads: timm's final ``norm`` + 1000-class ``head`` and ``refinenet4.resConfUnit1``
     (blocks.py:329-333 only runs resConfUnit1 when two inputs are given).
     """
+    if backbone == "vitl16_384":
+        return vitl16_state_dict_spec(num_channels, include_unused)
+    if backbone != "vitb_rn50_384":
+        raise ValueError(f"backbone must be one of {BACKBONES}")
     sp: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     vp = "pretrained.model."
     sp[vp + "cls_token"] = (1, 1, VIT_DIM)
@@ -153,6 +230,8 @@ def _gain_for(key: str, shape, family: str = "default") -> Tuple[str, float]:
     # weights
     if "patch_embed.backbone" in key:
         return "normal", 0.05  # standardised at run time: scale-free
+    if "act_postprocess" in key and key.endswith(".4.weight") and len(shape) == 4 and shape[2] in (2, 4):
+        return "normal", 1.0 / (shape[0] ** 0.5)  # ConvTranspose2d [Cin, Cout, k, k], k == stride: one tap per output pixel
     g = 1.0
     if "attn.proj" in key or "mlp.fc2" in key:
         g = (1.0 / (2 * VIT_DEPTH) ** 0.5) if family == "trained" else 0.5
@@ -168,15 +247,17 @@ def _gain_for(key: str, shape, family: str = "default") -> Tuple[str, float]:
 
 
 def random_state_dict(seed: int = 0, num_channels: int = 3, include_unused: bool = True,
-                      family: str = "default") -> Dict[str, torch.Tensor]:
+                      family: str = "default", backbone: str = "vitb_rn50_384") -> Dict[str, torch.Tensor]:
     """Deterministic synthetic fp32 weights (CPU generator => identical on every host).  `family`: see _gain_for."""
     if family not in FAMILIES:
         raise ValueError(f"family must be one of {FAMILIES}")
     g = torch.Generator(device="cpu")
     g.manual_seed(1000003 * int(seed) + 17)
     sd: Dict[str, torch.Tensor] = OrderedDict()
-    for key, shape in state_dict_spec(num_channels, include_unused).items():
+    for key, shape in state_dict_spec(num_channels, include_unused, backbone).items():
         kind, s = _gain_for(key, shape, family)
+        if backbone == "vitl16_384" and ("attn.proj" in key or "mlp.fc2" in key) and key.endswith(".weight") and family == "default":
+            s *= 0.7  # 24 residual blocks instead of 12: keep the token stream O(1)
         if kind == "const":
             t = torch.full(shape, s, dtype=torch.float32)
         elif kind == "gamma":

@@ -132,14 +132,14 @@ def resnetv2_backbone(x: Tensor, sd: Dict[str, Tensor], pre: str, taps: Optional
     return outs
 
 
-def vit_block(x: Tensor, sd: Dict[str, Tensor], p: str) -> Tensor:
+def vit_block(x: Tensor, sd: Dict[str, Tensor], p: str, heads: int = VIT_HEADS) -> Tensor:
     """timm Block: x += attn(norm1(x)); x += mlp(norm2(x)); LayerNorm eps 1e-6."""
     B, N, C = x.shape
     h = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)
     qkv = F.linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
-    qkv = qkv.reshape(B, N, 3, VIT_HEADS, C // VIT_HEADS).permute(2, 0, 3, 1, 4)
+    qkv = qkv.reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    attn = (q @ k.transpose(-2, -1)) * ((C // VIT_HEADS) ** -0.5)
+    attn = (q @ k.transpose(-2, -1)) * ((C // heads) ** -0.5)
     attn = attn.softmax(dim=-1)
     h = (attn @ v).transpose(1, 2).reshape(B, N, C)
     x = x + F.linear(h, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
@@ -238,6 +238,77 @@ def dpt_forward(sd: Dict[str, Tensor], x: Tensor, taps: Optional[dict] = None,
         taps.update(l3=layer_3, l4=layer_4, l1_rn=l1rn, l2_rn=l2rn, l3_rn=l3rn, l4_rn=l4rn,
                     p4=p4, p3=p3, p2=p2, p1=p1, h0=h0, h1=h1, pre=pre, out=out)
     return out.squeeze(dim=1)
+
+
+# ----------------------------------------------------------------- DPT-Large (vitl16_384)
+VITL_HOOKS = (5, 11, 17, 23)  # dpt_depth.py:41-45
+
+
+def _decoder_and_head(sd: Dict[str, Tensor], layers, taps: Optional[dict], non_negative: bool) -> Tensor:
+    """DPT.forward after forward_vit (dpt_depth.py:73-83) + the head (dpt_depth.py:91-99); shared with the hybrid."""
+    l1rn = F.conv2d(layers[0], sd["scratch.layer1_rn.weight"], None, padding=1)
+    l2rn = F.conv2d(layers[1], sd["scratch.layer2_rn.weight"], None, padding=1)
+    l3rn = F.conv2d(layers[2], sd["scratch.layer3_rn.weight"], None, padding=1)
+    l4rn = F.conv2d(layers[3], sd["scratch.layer4_rn.weight"], None, padding=1)
+    p4 = fusion(sd, "scratch.refinenet4.", l4rn)
+    p3 = fusion(sd, "scratch.refinenet3.", p4, l3rn)
+    p2 = fusion(sd, "scratch.refinenet2.", p3, l2rn)
+    p1 = fusion(sd, "scratch.refinenet1.", p2, l1rn)
+    oc = "scratch.output_conv."
+    h0 = F.conv2d(p1, sd[oc + "0.weight"], sd[oc + "0.bias"], padding=1)
+    h0u = F.interpolate(h0, scale_factor=2, mode="bilinear", align_corners=True)
+    h1 = F.relu(F.conv2d(h0u, sd[oc + "2.weight"], sd[oc + "2.bias"], padding=1))
+    pre = F.conv2d(h1, sd[oc + "4.weight"], sd[oc + "4.bias"])
+    out = F.relu(pre) if non_negative else pre
+    if taps is not None:
+        taps.update(l1=layers[0], l2=layers[1], l3=layers[2], l4=layers[3], l1_rn=l1rn, l2_rn=l2rn, l3_rn=l3rn, l4_rn=l4rn,
+                    p4=p4, p3=p3, p2=p2, p1=p1, h0=h0, h1=h1, pre=pre, out=out)
+    return out.squeeze(dim=1)
+
+
+@torch.no_grad()
+def dpt_forward_vitl16(sd: Dict[str, Tensor], x: Tensor, taps: Optional[dict] = None, non_negative: bool = True) -> Tensor:
+    """``DPTDepthModel(backbone='vitl16_384')`` (DPT-Large; demo.py:81, blocks.py:12-18): forward_flex on timm's
+    ``vit_large_patch16_384`` (vit.py:119-155: 16x16 stride-16 patch conv, cls, resized pos_embed, 24 blocks of width 1024
+    with 16 heads), hooks on blocks 5/11/17/23 (vit.py:299-309, dpt_depth.py:41-45), ProjectReadout + reassemble
+    (vit.py:176-260: 1x1 conv then ConvTranspose2d k4s4 / k2s2 / identity / Conv2d 3x3 s2 p1), then the decoder and head
+    the hybrid model uses.  State-dict keys: omnidata_amd.weights.vitl16_state_dict_spec."""
+    x = x.float()
+    B, _, H, W = x.shape
+    gh, gw = H // 16, W // 16
+    D, heads = 1024, 16
+    vp = "pretrained.model."
+    pos = sd[vp + "pos_embed"]
+    g_old = int(math.sqrt(pos.shape[1] - 1))
+    if (gh, gw) != (g_old, g_old):  # _resize_pos_embed vit.py:102-116
+        grid = pos[0, 1:].reshape(1, g_old, g_old, -1).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=(gh, gw), mode="bilinear")
+        pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)], dim=1)
+    t = F.conv2d(x, sd[vp + "patch_embed.proj.weight"], sd[vp + "patch_embed.proj.bias"], stride=16)
+    t = t.flatten(2).transpose(1, 2)
+    t = torch.cat((sd[vp + "cls_token"].expand(B, -1, -1), t), dim=1) + pos
+    if taps is not None:
+        taps["tok0"] = t
+    hooks = {}
+    for l in range(24):
+        t = vit_block(t, sd, f"{vp}blocks.{l}.", heads)
+        if taps is not None:
+            taps[f"blk{l}"] = t
+        if l in VITL_HOOKS:
+            hooks[l] = t
+    pp = "pretrained.act_postprocess"
+    layers = []
+    for n, l in enumerate(VITL_HOOKS, start=1):
+        r = project_readout(hooks[l], sd, f"{pp}{n}.0.").transpose(1, 2).reshape(B, D, gh, gw)
+        y = F.conv2d(r, sd[f"{pp}{n}.3.weight"], sd[f"{pp}{n}.3.bias"])
+        if n == 1:
+            y = F.conv_transpose2d(y, sd[f"{pp}1.4.weight"], sd[f"{pp}1.4.bias"], stride=4)
+        elif n == 2:
+            y = F.conv_transpose2d(y, sd[f"{pp}2.4.weight"], sd[f"{pp}2.4.bias"], stride=2)
+        elif n == 4:
+            y = F.conv2d(y, sd[f"{pp}4.4.weight"], sd[f"{pp}4.4.bias"], stride=2, padding=1)
+        layers.append(y)
+    return _decoder_and_head(sd, layers, taps, non_negative)
 
 
 # ------------------------------------------------------- parity metrics (SURVEY 8c)

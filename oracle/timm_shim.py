@@ -202,11 +202,39 @@ class VisionTransformer(nn.Module):
         self.head = nn.Linear(768, 1000)  # unused by DPT, but present in checkpoints
 
 
+class PatchEmbed(nn.Module):
+    """timm 0.4.12 PatchEmbed: Conv2d(3, embed_dim, kernel_size=patch, stride=patch) -> flatten(2).transpose(1, 2)."""
+
+    def __init__(self, patch_size=16, embed_dim=1024):
+        super().__init__()
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class PlainVisionTransformer(nn.Module):
+    """timm 0.4.12 vit_large_patch16_384: patch 16, embed 1024, depth 24, heads 16, mlp_ratio 4, qkv_bias, LayerNorm
+    eps 1e-6 (the reference consumes .patch_embed.proj, .cls_token, .pos_embed, .pos_drop, .blocks, .norm: vit.py:119-155)."""
+
+    def __init__(self, embed_dim=1024, depth=24, num_heads=16):
+        super().__init__()
+        self.patch_embed = PatchEmbed(16, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, 577, embed_dim))
+        self.pos_drop = nn.Dropout(p=0.0)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.head = nn.Linear(embed_dim, 1000)  # unused by DPT, but present in checkpoints
+
+
 def create_model(name, pretrained=False, **kwargs):
-    if name != "vit_base_resnet50_384":
-        raise RuntimeError(f"timm shim only provides vit_base_resnet50_384, not {name}")
     # `pretrained` is ignored: dpt_depth.py:51 hard-codes True, which would download.
-    return VisionTransformer()
+    if name == "vit_base_resnet50_384":
+        return VisionTransformer()
+    if name == "vit_large_patch16_384":
+        return PlainVisionTransformer(1024, 24, 16)
+    raise RuntimeError(f"timm shim provides vit_base_resnet50_384 and vit_large_patch16_384, not {name}")
 
 
 def install():

@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference/omnidata_tools/torch"
 
 from oracle import timm_shim  # noqa: E402
-from oracle.dpt_oracle import dpt_forward  # noqa: E402
+from oracle.dpt_oracle import dpt_forward, dpt_forward_vitl16  # noqa: E402
 from omnidata_amd.weights import random_state_dict, state_dict_spec, synthetic_input  # noqa: E402
 
 GOLDEN_TAPS = ("stem", "s0", "s1", "s2", "tok0", "blk0", "blk8", "blk11", "l3", "l4",
@@ -106,6 +106,43 @@ def main():
                 out["stat_" + name] = stats(taps[name])
             fname = f"dpt_{task}_seed{seed}.npz" if (H, W) == (384, 384) else f"flex_{task}_seed{seed}_{H}x{W}.npz"
             path = os.path.join(ROOT, "tests", "golden", fname)
+            np.savez_compressed(path, **out)
+            print("    wrote", path, os.path.getsize(path), "bytes")
+    # ---- DPT-Large (backbone='vitl16_384', demo.py:81): one depth case -> tests/golden/vitl16_depth_seed5.npz
+    VITL_TAPS = ("tok0", "blk5", "blk23", "l1", "l2", "l3", "l4", "l1_rn", "l4_rn", "p4", "p1", "h0", "h1", "pre")
+    for task, C, seed, B in [("depth", 1, 5, 1)]:
+        model = DPTDepthModel(backbone="vitl16_384", num_channels=C).eval()
+        ref_sd = model.state_dict()
+        spec = state_dict_spec(C, True, "vitl16_384")
+        assert set(ref_sd.keys()) == set(spec.keys()), set(ref_sd.keys()) ^ set(spec.keys())
+        for k, shp in spec.items():
+            assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+        sd = random_state_dict(seed, C, backbone="vitl16_384")
+        model.load_state_dict(sd, strict=True)
+        x = synthetic_input(seed, B, task)
+        with torch.no_grad():
+            y_ref = model(x)
+        acts = ref_vit.activations
+        taps = {}
+        y_or = dpt_forward_vitl16(sd, x, taps)
+        d_out = (y_ref - y_or).abs().max().item()
+        d_h = [(acts[str(i + 1)] - taps[f"blk{l}"]).abs().max().item() for i, l in enumerate((5, 11, 17, 23))]
+        worst = max(worst, d_out)
+        print(f"[vitl16_384 {task} seed={seed} B={B}] ref-vs-oracle max|d|: out={d_out:.3e} hooks={['%.2e' % v for v in d_h]}; "
+              f"out mean={y_ref.mean():.4f} std={y_ref.std():.4f} min={y_ref.min():.4f} max={y_ref.max():.4f} "
+              f"frac0={(y_ref == 0).float().mean():.4f}")
+        for name in VITL_TAPS:
+            t = taps[name]
+            print(f"    tap {name:6s} shape={tuple(t.shape)} mean={t.mean():+.3f} std={t.std():.3f} absmax={t.abs().max():.2f}")
+        assert d_out < 2e-4, d_out
+        if not args.no_write:
+            out = {"task": task, "num_channels": C, "seed": seed, "batch": B, "backbone": "vitl16_384",
+                   "out_sub": subsample(y_ref), "out_stats": stats(y_ref), "height": 384, "width": 384,
+                   "out_row": y_ref.reshape(B, -1, 384, 384)[0, 0, 191].numpy().astype(np.float32)}
+            for name in VITL_TAPS:
+                out["tap_" + name] = subsample(taps[name])
+                out["stat_" + name] = stats(taps[name])
+            path = os.path.join(ROOT, "tests", "golden", f"vitl16_{task}_seed{seed}.npz")
             np.savez_compressed(path, **out)
             print("    wrote", path, os.path.getsize(path), "bytes")
     print("worst ref-vs-oracle output difference:", worst)

@@ -38,6 +38,24 @@ def test_oracle_matches_reference_golden(path):
         np.testing.assert_allclose(subsample(taps[name]), ref, atol=3e-5 * scale, rtol=0, err_msg=name)
 
 
+def test_vitl16_oracle_matches_reference_golden():
+    """DPT-Large (backbone='vitl16_384'): the functional oracle against the vector produced by the reference's own
+    DPTDepthModel(backbone='vitl16_384') (oracle/validate_vs_reference.py)."""
+    from oracle.dpt_oracle import dpt_forward_vitl16
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vitl16_depth_seed5.npz"))
+    seed, B = int(g["seed"]), int(g["batch"])
+    torch.set_num_threads(os.cpu_count())
+    taps = {}
+    y = dpt_forward_vitl16(random_state_dict(seed, 1, backbone="vitl16_384"), synthetic_input(seed, B, "depth"), taps)
+    assert tuple(y.shape) == (B, 384, 384)
+    np.testing.assert_allclose(subsample(y), g["out_sub"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(y.reshape(B, -1, 384, 384)[0, 0, 191].numpy(), g["out_row"], atol=2e-5, rtol=0)
+    for name in ("tok0", "blk5", "blk23", "l1", "l2", "l3", "l4", "p4", "p1", "h0", "pre"):
+        ref = g["tap_" + name]
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(subsample(taps[name]), ref, atol=3e-5 * scale, rtol=0, err_msg=name)
+
+
 def test_metrics_helpers():
     a = torch.rand(2, 16, 16)
     assert torch.allclose(ssi_align(3 * a + 0.5, a), a, atol=1e-5)
