@@ -32,6 +32,9 @@ sys.path.insert(0, ROOT)
 # "dual" = BASELINE.json configs[4]: both tasks from one encoder pass, per image (185.29 GMAC)
 GFLOP_PER_IMAGE = {"normal": 255.25, "depth": 255.23, "dual": 370.58}          # SURVEY.md 8d (algorithmic)
 GEMM_GMAC_PER_IMAGE = {"normal": 121.487, "depth": 121.478, "dual": 179.153}  # A.6: convs + linears (attention excluded)
+# --backbone vitl16_384 (DPT-Large; not the headline configuration): 258.21 GMAC/image, 16.36 of them attention
+GFLOP_LARGE = {"normal": 516.43, "depth": 516.41}
+GEMM_GMAC_LARGE = {"normal": 241.855, "depth": 241.845}
 PEAK_TFLOPS = 2500.0                                           # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
@@ -50,6 +53,8 @@ def main():
     ap.add_argument("--parity-x3-groups", default="")
     ap.add_argument("--io", default="fp32", choices=["fp32", "bf16", "fp16"], help="element type of the caller-side image and "
                     "result tensors (SURVEY.md 8d config 2 feeds bf16; fp32 is the reference's drop-in convention)")
+    ap.add_argument("--backbone", default="vitb_rn50_384", choices=["vitb_rn50_384", "vitl16_384"],
+                    help="vitb_rn50_384 = DPT-Hybrid (BASELINE.json's configuration, the default); vitl16_384 = DPT-Large")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
@@ -83,9 +88,16 @@ def main():
     from omnidata_amd.weights import random_dual_state_dict, random_state_dict, synthetic_input
 
     dual = args.task == "dual"
+    large = args.backbone == "vitl16_384"
+    if large and dual:
+        raise SystemExit("the dual-task model is DPT-Hybrid")
+    if large:
+        GFLOP_PER_IMAGE.update(GFLOP_LARGE)
+        GEMM_GMAC_PER_IMAGE.update(GEMM_GMAC_LARGE)
     C = 1 if args.task == "depth" else 3
-    make_sd = (lambda: random_dual_state_dict(0)) if dual else (lambda: random_state_dict(0, C))
-    eng = build_replicated_engine(make_sd, C, args.batch, args.dtype, local_rank, dual=dual, x3_groups=args.x3_groups)
+    make_sd = (lambda: random_dual_state_dict(0)) if dual else (lambda: random_state_dict(0, C, backbone=args.backbone))
+    eng = build_replicated_engine(make_sd, C, args.batch, args.dtype, local_rank, dual=dual, x3_groups=args.x3_groups,
+                                  backbone=args.backbone)
     io_dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.io]
     x = synthetic_input(1000 + rank, args.batch, "normal" if dual else args.task).to(device).to(io_dt)
     y = torch.empty(args.batch, C, 384, 384, dtype=io_dt, device=device)
@@ -137,14 +149,11 @@ def main():
         # figure is the committed rocprofv3 measurement of this very command (profiles/README.md), scaled
         # from its batch to this one; null when no measurement is committed for the dtype.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.dtype == "bf16":
-            tj = json.load(open(tpath))
-            traffic = round(tj["gemm_family_hbm_bytes_per_launch"] * args.batch / 32.0)
-        tpath2 = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(tpath2) and args.dtype == "bf16":
-            tj = json.load(open(tpath2))
-            traffic = round(tj["gemm_family_hbm_bytes_per_launch"] * args.batch / 32.0)
+        for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed round wins
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath) and args.dtype == "bf16" and not large:
+                tj = json.load(open(tpath))
+                traffic = round(tj["gemm_family_hbm_bytes_per_launch"] * args.batch / 32.0)
         roofline = {"bound": "mfma", "kernel": "dptx::gemm_kernel (implicit-GEMM MFMA, all conv/linear launches)",
                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
@@ -159,8 +168,10 @@ def main():
     parity = None
     oracle_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.dpt_oracle import dpt_forward, dpt_forward_dual
+        from oracle.dpt_oracle import dpt_forward, dpt_forward_dual, dpt_forward_vitl16
         sd = make_sd()
+        if large:
+            dpt_forward = dpt_forward_vitl16  # noqa: F811
         if dual:
             dpt_forward = dpt_forward_dual  # noqa: F811  (the reference forward twice, encoder weights tied)
         xc = synthetic_input(1000, 4, "normal" if dual else args.task)
@@ -208,7 +219,7 @@ def main():
         if args.parity_dtype != "none" and args.parity_dtype != args.dtype:
             from omnidata_amd.engine import Engine
             pe = Engine(num_channels=C, max_batch=args.batch, dtype=args.parity_dtype, device_id=local_rank, dual=dual,
-                        x3_groups=args.parity_x3_groups)
+                        x3_groups=args.parity_x3_groups, backbone=args.backbone)
             pe.load_state_dict(sd)
             pm = max_abs(pe, oracle_ref)
             fwd = (lambda: pe.forward_dual(x, out_normal=y, out_depth=y2)) if dual else (lambda: pe.forward(x, out=y))
@@ -231,16 +242,18 @@ def main():
         total_images = args.batch * world * args.steps
         value = total_images / elapsed
         e2e_tflops = value * GFLOP_PER_IMAGE[args.task] / 1e3
+        arch = "DPT-Large" if large else "DPT-Hybrid"
         line = {
-            "metric": {"normal": "images/sec (384x384) DPT-Hybrid surface-normal inference",
-                       "depth": "images/sec (384x384) DPT-Hybrid depth inference",
+            "metric": {"normal": f"images/sec (384x384) {arch} surface-normal inference",
+                       "depth": f"images/sec (384x384) {arch} depth inference",
                        "dual": "images/sec (384x384) DPT-Hybrid dual-task normal+depth, shared encoder"}[args.task],
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "io_dtype": args.io,
             "data": "synthetic 384x384 inputs resident in HBM; seeded random weights",
-            "config": {"workload": f"DPT-Hybrid-384 {args.task}, batch {args.batch}/GPU, {args.dtype}, {world}xMI355X "
-                                   f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+            "config": {"workload": f"{arch}-384 {args.task}, batch {args.batch}/GPU, {args.dtype}, {world}xMI355X "
+                                   + ("(backbone vitl16_384: SURVEY.md 8f row 3, not a BASELINE.json configuration)" if large else
+                                      f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])"), "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"replicas x{world} (no collective in the loop)",
                        "schedule": "each forward = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)"},
             "e2e_mfma_frac": round(e2e_tflops / (PEAK_TFLOPS * world), 4),

@@ -65,6 +65,8 @@ enum { DPTX_GROUP_RESNET = 1,      /* stem + ResNetV2 stages (convs and GroupNor
        DPTX_GROUP_FUSION = 32,     /* scratch.refinenet4..1                                    */
        DPTX_GROUP_HEAD = 64,       /* scratch.output_conv                                      */
        DPTX_GROUP_ALL = 127 };
+/* backbones behind the same ABI (dpt_depth.py:27-35 `backbone=`) */
+enum { DPTX_BACKBONE_VITB_RN50_384 = 0, DPTX_BACKBONE_VITL16_384 = 1 };
 /* element type of the caller-side image AND result buffers of one forward call (`x_dtype`): fp32 is the drop-in default
  * (the reference feeds and returns fp32 tensors); with BF16 / FP16 the stem reads and the head writes 16-bit NCHW
  * tensors directly (SURVEY.md 8d config 2 feeds bf16) -- half the bytes at the boundary, no conversion pass. */
@@ -85,7 +87,9 @@ typedef struct dptx_config {
                          /*   forked from / joined to the caller's stream (same bits, faster); 1: caller's stream only */
   int32_t x3_groups;     /* dtype MIXED: OR of DPTX_GROUP_* that run with 3 MFMAs per product; 0 = the default policy  */
                          /*   (everything except the ViT blocks).  Ignored by the other dtypes.                      */
-  int32_t reserved[3];   /* must be zero                                                        */
+  int32_t backbone;      /* DPTX_BACKBONE_*: 0 = vitb_rn50_384 (DPT-Hybrid, the default), 1 = vitl16_384 (DPT-Large:  */
+                         /*   dpt_depth.py:41-45 hooks [5,11,17,23], blocks.py:12-18, vit.py:176-309; demo.py:81)       */
+  int32_t reserved[2];   /* must be zero                                                        */
 } dptx_config;
 
 /* Fills *cfg with the reference defaults: C=3, max_batch=32, bf16, device 0, non_negative=1,

@@ -27,9 +27,6 @@ namespace {
 
 constexpr int IMG = 384;
 constexpr int S_TOK = 577;
-constexpr int D_VIT = 768;
-constexpr int D_MLP = 3072;
-constexpr int N_HEADS = 12;
 constexpr int FEAT = 256;
 const int STAGE_DEPTH[3] = {3, 4, 9};
 const int STAGE_OUT[3] = {256, 512, 1024};
@@ -109,7 +106,9 @@ inline uint8_t f32_to_e4m3(float f) {
 }
 
 // --------------------------------------------------------------------------- weight spec
-enum Role { R_STDCONV, R_CONV, R_LINEAR, R_VEC, R_HEAD4, R_UNUSED };
+// R_DECONV: ConvTranspose2d [Cin, Cout, k, k] with kernel == stride, packed as the GEMM operand [(dy*k+dx)*Cout + co][ci];
+// R_DECONV_BIAS: its bias, tiled k*k times so that the GEMM epilogue can add it per column
+enum Role { R_STDCONV, R_CONV, R_LINEAR, R_VEC, R_HEAD4, R_UNUSED, R_DECONV, R_DECONV_BIAS };
 struct Spec {
   std::string key;
   std::vector<int64_t> shape;
@@ -121,9 +120,49 @@ void add(std::vector<Spec>& v, const std::string& k, std::vector<int64_t> s, Rol
 // Mirrors omnidata_amd/weights.py:state_dict_spec (reference key names).
 // `dual`: a second decoder (depth, 1 channel) under "depth.scratch.*" next to the normal one (3 channels) under
 // "scratch.*"; both read the one shared encoder "pretrained.*" (SURVEY.md 8d config 5).
-std::vector<Spec> build_spec(int C, bool dual) {
+// backbone 0: vitb_rn50_384 (DPT-Hybrid); 1: vitl16_384 (DPT-Large; omnidata_amd/weights.py
+// vitl16_state_dict_spec)
+std::vector<Spec> build_spec(int C, bool dual, int backbone) {
   std::vector<Spec> v;
   const std::string vp = "pretrained.model.";
+  const int D_VIT = backbone == 1 ? 1024 : 768, D_MLP = 4 * D_VIT, depth = backbone == 1 ? 24 : 12;
+  if (backbone == 1) {
+    add(v, vp + "cls_token", {1, 1, D_VIT}, R_VEC);
+    add(v, vp + "pos_embed", {1, S_TOK, D_VIT}, R_VEC);
+    add(v, vp + "patch_embed.proj.weight", {D_VIT, 3, 16, 16}, R_LINEAR);  // flattened (c, ky, kx) = the patch matrix's k order
+    add(v, vp + "patch_embed.proj.bias", {D_VIT}, R_VEC);
+    for (int l = 0; l < depth; ++l) {
+      const std::string p = vp + "blocks." + std::to_string(l) + ".";
+      add(v, p + "norm1.weight", {D_VIT}, R_VEC);
+      add(v, p + "norm1.bias", {D_VIT}, R_VEC);
+      add(v, p + "attn.qkv.weight", {3 * D_VIT, D_VIT}, R_LINEAR);
+      add(v, p + "attn.qkv.bias", {3 * D_VIT}, R_VEC);
+      add(v, p + "attn.proj.weight", {D_VIT, D_VIT}, R_LINEAR);
+      add(v, p + "attn.proj.bias", {D_VIT}, R_VEC);
+      add(v, p + "norm2.weight", {D_VIT}, R_VEC);
+      add(v, p + "norm2.bias", {D_VIT}, R_VEC);
+      add(v, p + "mlp.fc1.weight", {D_MLP, D_VIT}, R_LINEAR);
+      add(v, p + "mlp.fc1.bias", {D_MLP}, R_VEC);
+      add(v, p + "mlp.fc2.weight", {D_VIT, D_MLP}, R_LINEAR);
+      add(v, p + "mlp.fc2.bias", {D_VIT}, R_VEC);
+    }
+    add(v, vp + "norm.weight", {D_VIT}, R_UNUSED);
+    add(v, vp + "norm.bias", {D_VIT}, R_UNUSED);
+    add(v, vp + "head.weight", {1000, D_VIT}, R_UNUSED);
+    add(v, vp + "head.bias", {1000}, R_UNUSED);
+    const int feats[4] = {256, 512, 1024, 1024};
+    for (int n = 1; n <= 4; ++n) {
+      const std::string p = "pretrained.act_postprocess" + std::to_string(n) + ".";
+      const int f = feats[n - 1];
+      add(v, p + "0.project.0.weight", {D_VIT, 2 * D_VIT}, R_LINEAR);
+      add(v, p + "0.project.0.bias", {D_VIT}, R_VEC);
+      add(v, p + "3.weight", {f, D_VIT, 1, 1}, R_CONV);
+      add(v, p + "3.bias", {f}, R_VEC);
+      if (n == 1) { add(v, p + "4.weight", {f, f, 4, 4}, R_DECONV); add(v, p + "4.bias", {f}, R_DECONV_BIAS); }
+      if (n == 2) { add(v, p + "4.weight", {f, f, 2, 2}, R_DECONV); add(v, p + "4.bias", {f}, R_DECONV_BIAS); }
+      if (n == 4) { add(v, p + "4.weight", {f, f, 3, 3}, R_CONV); add(v, p + "4.bias", {f}, R_VEC); }
+    }
+  } else {
   add(v, vp + "cls_token", {1, 1, D_VIT}, R_VEC);
   add(v, vp + "pos_embed", {1, S_TOK, D_VIT}, R_VEC);
   const std::string bp = vp + "patch_embed.backbone.";
@@ -154,7 +193,7 @@ std::vector<Spec> build_spec(int C, bool dual) {
   }
   add(v, vp + "patch_embed.proj.weight", {D_VIT, 1024, 1, 1}, R_CONV);
   add(v, vp + "patch_embed.proj.bias", {D_VIT}, R_VEC);
-  for (int l = 0; l < 12; ++l) {
+  for (int l = 0; l < depth; ++l) {
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
     add(v, p + "norm1.weight", {D_VIT}, R_VEC);
     add(v, p + "norm1.bias", {D_VIT}, R_VEC);
@@ -184,8 +223,9 @@ std::vector<Spec> build_spec(int C, bool dual) {
       add(v, p + "4.bias", {D_VIT}, R_VEC);
     }
   }
+  }  // backbone
   auto decoder = [&](const std::string& pre, int ch) {
-    const int rn_in[4] = {256, 512, 768, 768};
+    const int rn_in[4] = {256, 512, D_VIT, D_VIT};
     for (int i = 1; i <= 4; ++i) add(v, pre + "scratch.layer" + std::to_string(i) + "_rn.weight", {FEAT, rn_in[i - 1], 3, 3}, R_CONV);
     for (int i = 1; i <= 4; ++i) {
       const std::string p = pre + "scratch.refinenet" + std::to_string(i) + ".";
@@ -226,9 +266,11 @@ size_t packed_entry_bytes(const Spec& s) {
       if (s.shape[3] == 7) return (size_t)s.shape[0] * STEM_K * 2;
       return numel(s.shape) * 2;
     case R_CONV:
+    case R_DECONV:
     case R_LINEAR: return numel(s.shape) * 2;
     case R_VEC:
     case R_HEAD4: return numel(s.shape) * 4;
+    case R_DECONV_BIAS: return numel(s.shape) * 4 * 16;  // room for the 4x4 case (the 2x2 one uses a quarter)
     default: return 0;
   }
 }
@@ -248,6 +290,8 @@ struct TapInfo {
 
 struct dptx_engine {
   dptx_config cfg;
+  int backbone = 0;                              // 0 vitb_rn50_384, 1 vitl16_384
+  int dv = 768, dm = 3072, nh = 12, depth = 12;  // ViT width, MLP width, heads, blocks
   std::vector<Spec> spec;
   std::unordered_map<std::string, size_t> spec_index;
   std::unordered_map<std::string, size_t> packed_off;  // byte offset inside the blob
@@ -358,6 +402,7 @@ size_t plan_arena_for(dptx_engine* e, size_t B, bool half) {
   // every buffer scales with the pixel count of the largest supported input (H, W multiples of 32); P = H*W
   const size_t P = (size_t)e->max_h * e->max_w;
   const size_t p2 = P / 4, p4 = P / 16, p8 = P / 64, p16 = P / 256, p32 = P / 1024, S = p16 + 1;
+  const size_t DV = (size_t)e->dv;
   size_t off = 0;
   auto take = [&](Buf& b, size_t elems, size_t esz) {
     const size_t bytes = align_up(elems * esz, 256);
@@ -376,18 +421,18 @@ size_t plan_arena_for(dptx_engine* e, size_t B, bool half) {
   take(e->DS, B * p4 * 256, 2);
   // GroupNorm partial records (32 groups x float2): p2/256 chunks for the stem, p4/32 MFMA row blocks for a stage conv
   for (int i = 0; i < 4; ++i) take(e->part[i], B * (std::max(p2 / 256, p4 / 32) + 64) * 64, 4);
-  take(e->X, B * S * D_VIT, 4);
-  take(e->Hn, B * S * D_VIT, 2);
-  take(e->QKV, B * S * 3 * D_VIT, 2);
-  take(e->AO, B * S * D_VIT, 2);
-  take(e->F1, B * S * D_MLP, 2);
-  take(e->R3, B * p16 * D_VIT, 2);
-  take(e->R4, B * p16 * D_VIT, 2);
-  take(e->L3, B * p16 * D_VIT, 2);
-  take(e->T4, B * p16 * D_VIT, 2);
-  take(e->L4, B * p32 * D_VIT, 2);
-  take(e->clsb, B * D_VIT, 4);
-  take(e->pos_alt, S * D_VIT, 4);  // bilinearly resized pos_embed for inputs other than 384x384
+  take(e->X, B * S * DV, 4);
+  take(e->Hn, B * S * DV, 2);
+  take(e->QKV, B * S * 3 * DV, 2);
+  take(e->AO, B * S * DV, 2);
+  take(e->F1, B * S * (size_t)e->dm, 2);
+  take(e->R3, B * p16 * DV, 2);
+  take(e->R4, B * p16 * DV, 2);
+  take(e->L3, B * p16 * DV, 2);
+  take(e->T4, B * p16 * DV, 2);
+  take(e->L4, B * p32 * DV, 2);
+  take(e->clsb, B * DV, 4);
+  take(e->pos_alt, S * DV, 4);  // bilinearly resized pos_embed for inputs other than 384x384
   const size_t rn_px[4] = {p4, p8, p16, p32};
   for (int i = 0; i < 4; ++i) take(e->lrn[i], B * rn_px[i] * FEAT, 2);
   take(e->tA, B * p4 * FEAT, 2);
@@ -445,9 +490,22 @@ int pack_host(dptx_engine* e) {
       memcpy(dst, src.data(), src.size() * 4);
       continue;
     }
+    if (s.role == R_DECONV_BIAS) {  // bias[co] for every one of the (up to 16) taps: column (tap*Cout + co) of the GEMM
+      for (int t = 0; t < 16; ++t) memcpy(dst + (size_t)t * src.size() * 4, src.data(), src.size() * 4);
+      continue;
+    }
     uint16_t* d16 = (uint16_t*)dst;
     if (s.role == R_LINEAR) {
       for (size_t i = 0; i < src.size(); ++i) put(d16, i, src[i]);
+      continue;
+    }
+    if (s.role == R_DECONV) {  // [Cin][Cout][k][k] -> GEMM operand W[(dy*k + dx)*Cout + co][ci]
+      const int CI = (int)s.shape[0], CO = (int)s.shape[1], K = (int)s.shape[2];
+      for (int ci = 0; ci < CI; ++ci)
+        for (int co = 0; co < CO; ++co)
+          for (int dy = 0; dy < K; ++dy)
+            for (int dx = 0; dx < K; ++dx)
+              put(d16, ((size_t)(dy * K + dx) * CO + co) * CI + ci, src[(((size_t)ci * CO + co) * K + dy) * K + dx]);
       continue;
     }
     // convolution OIHW -> [O][kh][kw][I]; StdConv2dSame weights are standardised first
@@ -617,6 +675,8 @@ int Run::forward(const void* x, void* y, void* y2) {
   }
   const std::string vp = "pretrained.model.";
   const std::string bp = vp + "patch_embed.backbone.";
+  const int D_VIT = E->dv, D_MLP = E->dm, N_HEADS = E->nh;
+  const bool large = E->backbone == DPTX_BACKBONE_VITL16_384;
   float* part0 = (float*)A(E->part[0]);
   float* part1 = (float*)A(E->part[1]);
   float* part2 = (float*)A(E->part[2]);
@@ -631,6 +691,7 @@ int Run::forward(const void* x, void* y, void* y2) {
     pos = (const float*)A(E->pos_alt);
   }
 
+  if (!large) {
   // ---- stem: fused conv7x7 s2 SAME (stem.hip, no im2col) -> GN+ReLU -> MaxPool2dSame(3,2) ---------
   group(DPTX_GROUP_RESNET);
   chk(launch_stem_conv(dt, x, io, E->w(bp + "stem.conv.weight"), A(E->sraw), B, Hi, Wi, E->pl, st), "stem.conv", 0);
@@ -682,19 +743,24 @@ int Run::forward(const void* x, void* y, void* y2) {
     const char* names[3] = {"s0", "s1", "s2"};
     tap(names[s], cur, H, Wd, cout);
   }
+  }  // !large
 
   // ---- tokens: 1x1 proj + bias + pos_embed -> fp32 stream X[b*S + 1 + p] (S = 577 at 384x384); cls rows ----
   float* X = (float*)A(E->X);
   group(DPTX_GROUP_EMBED);
   {
+    // hybrid: the 1x1 projection of the ResNet's 1/16-resolution map (K = 1024); DPT-Large: timm PatchEmbed, a 16x16
+    // stride-16 convolution = a dense GEMM over the patch matrix (K = 3*16*16 = 768, misc.hip patchify16)
+    const int Kp = large ? 768 : 1024;
+    if (large) chk(launch_patchify16(dt, x, io, A(E->Hn), B, Hi, Wi, E->pl, st), "patchify");
     GemmParams p;
-    gemm_params_dense(p, B * NP, D_VIT, 1024);
-    p.A = A(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
+    gemm_params_dense(p, B * NP, D_VIT, Kp);
+    p.A = large ? A(E->Hn) : A(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
     p.bias = E->f(vp + "patch_embed.proj.bias");
     p.c_rpi = NP; p.c_img_rows = S; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
     p.R2 = pos; p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
-    exec_macs += (double)NP * D_VIT * 1024;
-    cat_macs[0] += (double)NP * D_VIT * 1024;
+    exec_macs += (double)NP * D_VIT * Kp;
+    cat_macs[0] += (double)NP * D_VIT * Kp;
     chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
   }
   chk(launch_cls_rows(E->f(vp + "cls_token"), pos, X, B, S, D_VIT, st), "cls_rows");
@@ -719,7 +785,8 @@ int Run::forward(const void* x, void* y, void* y2) {
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
   };
 
-  // ProjectReadout + reassemble for hook n (3 -> block 8, 4 -> block 11)
+  // ProjectReadout + reassemble for hook n (hybrid: 3 -> block 8, 4 -> block 11; DPT-Large: 1..4 -> blocks 5, 11, 17, 23,
+  // n = 1, 2 followed by a ConvTranspose2d with kernel == stride: a GEMM whose N enumerates (dy, dx, co) + a re-layout)
   auto readout = [&](int n) {
     group(DPTX_GROUP_REASSEMBLE);
     const std::string pp = "pretrained.act_postprocess" + std::to_string(n) + ".";
@@ -730,7 +797,7 @@ int Run::forward(const void* x, void* y, void* y2) {
     // the token GEMM reads a 16-bit image of the fp32 stream (Hn is free between blocks)
     chk(launch_cast_f32(dt, X, A(E->Hn), (size_t)B * S * D_VIT, E->pl, st), "readout_cast");
     exec_macs += (double)D_VIT * D_VIT;  // per image
-    void* R = (n == 3) ? A(E->R3) : A(E->R4);
+    void* R = (n & 1) ? A(E->R3) : A(E->R4);
     GemmParams p{};
     p.A = A(E->Hn); p.a_bytes = (long long)B * S * D_VIT * 2; p.planes = E->pl;
     p.W = E->w(pp + "0.project.0.weight"); p.ldw = 2 * D_VIT; p.C = R;
@@ -743,7 +810,18 @@ int Run::forward(const void* x, void* y, void* y2) {
     exec_macs += (double)NP * D_VIT * D_VIT;
     cat_macs[0] += (double)NP * D_VIT * D_VIT;
     chk(launch_gemm(dt, p, st), "readout", 0);
-    if (n == 3) {
+    if (n <= 2) {
+      const int f = n == 1 ? 256 : 512, k = n == 1 ? 4 : 2;
+      conv(R, gh, gw, D_VIT, pp + "3.weight", 1, 1, 0, 0, gh, gw, f, A(E->T4), E->f(pp + "3.bias"), 0, 0);
+      GemmParams d;
+      gemm_params_dense(d, B * NP, k * k * f, f);
+      d.A = A(E->T4); d.W = E->w(pp + "4.weight"); d.C = A(E->F1); d.bias = E->f(pp + "4.bias"); d.planes = E->pl;
+      exec_macs += (double)NP * k * k * f * f;
+      cat_macs[0] += (double)NP * k * k * f * f;
+      chk(launch_gemm(dt, d, st), "reassemble.deconv", 0);
+      chk(launch_depth_to_space(dt, A(E->F1), A(E->S[n - 1]), B, gh, gw, k, f, E->pl, st), "reassemble.d2s");
+      tap(n == 1 ? "l1" : "l2", A(E->S[n - 1]), gh * k, gw * k, f);
+    } else if (n == 3) {
       conv(R, gh, gw, D_VIT, pp + "3.weight", 1, 1, 0, 0, gh, gw, D_VIT, A(E->L3), E->f(pp + "3.bias"), 0, 0);
       tap("l3", A(E->L3), gh, gw, D_VIT);
     } else {
@@ -753,8 +831,8 @@ int Run::forward(const void* x, void* y, void* y2) {
     }
   };
 
-  // ---- 12 transformer blocks (timm Block; LN eps 1e-6) -----------------------------------
-  for (int l = 0; l < 12; ++l) {
+  // ---- 12 (24) transformer blocks (timm Block; LN eps 1e-6) -------------------------------
+  for (int l = 0; l < E->depth; ++l) {
     group(DPTX_GROUP_VIT);
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
     chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
@@ -771,8 +849,12 @@ int Run::forward(const void* x, void* y, void* y2) {
       snprintf(nm, sizeof nm, "blk%d", l);
       tok_tap(l + 1, nm);
     }
-    if (l == 8) readout(3);
-    if (l == 11) readout(4);
+    if (large) {
+      if (l % 6 == 5) readout(l / 6 + 1);  // dpt_depth.py:41-45 hooks [5, 11, 17, 23]
+    } else {
+      if (l == 8) readout(3);  // hooks [0, 1, 8, 11]: the first two are the ResNet stages
+      if (l == 11) readout(4);
+    }
   }
   // timm's final model.norm is dead compute in the reference (vit.py:153, result discarded :64)
 
@@ -783,7 +865,7 @@ int Run::forward(const void* x, void* y, void* y2) {
   const void* rn_in[4] = {A(E->S[0]), A(E->S[1]), A(E->L3), A(E->L4)};
   const int rn_h[4] = {h4, Hi / 8, gh, h32};
   const int rn_w[4] = {w4, Wi / 8, gw, w32};
-  const int rn_c[4] = {256, 512, 768, 768};
+  const int rn_c[4] = {256, 512, D_VIT, D_VIT};
   const char* rn_names[4] = {"l1_rn", "l2_rn", "l3_rn", "l4_rn"};
   group(DPTX_GROUP_RN);
   for (int i = 0; i < 4; ++i) {
@@ -878,6 +960,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (max_h < 64 || max_w < 64 || max_h % 32 != 0 || max_w % 32 != 0 || max_h > 4096 || max_w > 4096) return DPTX_E_INVALID;
   if ((long long)cfg->max_batch * max_h * max_w * 256 >= (1ll << 31)) return DPTX_E_INVALID;  // = max_batch <= 56 at 384x384
   if (cfg->streams < 0 || cfg->streams > 4) return DPTX_E_INVALID;
+  if (cfg->backbone != DPTX_BACKBONE_VITB_RN50_384 && cfg->backbone != DPTX_BACKBONE_VITL16_384) return DPTX_E_INVALID;
+  if (cfg->backbone == DPTX_BACKBONE_VITL16_384 && cfg->dual_task) return DPTX_E_INVALID;  // the dual-task model is the hybrid
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_FP8 || (cfg->ws_form != 0 && cfg->ws_form != 1))
@@ -886,6 +970,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (cfg->dtype == DPTX_DTYPE_MIXED) {
     x3_groups = cfg->x3_groups ? cfg->x3_groups : (DPTX_GROUP_ALL & ~DPTX_GROUP_VIT);
     if (x3_groups & ~DPTX_GROUP_ALL) return DPTX_E_INVALID;
+    if (cfg->backbone == DPTX_BACKBONE_VITL16_384) x3_groups |= DPTX_GROUP_RESNET;  // no such layers: nothing depends on them
     // a 3-MFMA group reads the lo planes of its inputs: every producer of those must be a 3-MFMA group as well
     auto needs = [&](int g, int producers) { return !(x3_groups & g) || (x3_groups & producers) == producers; };
     if (!needs(DPTX_GROUP_EMBED, DPTX_GROUP_RESNET) || !needs(DPTX_GROUP_RN, DPTX_GROUP_RESNET | DPTX_GROUP_REASSEMBLE) ||
@@ -896,6 +981,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (!e) return DPTX_E_ALLOC;
   e->cfg = *cfg;
   e->cfg.x3_groups = x3_groups;
+  e->backbone = cfg->backbone;
+  if (e->backbone == DPTX_BACKBONE_VITL16_384) { e->dv = 1024; e->dm = 4096; e->nh = 16; e->depth = 24; }
   e->max_h = max_h;
   {
     const char* t = getenv("DPTX_STREAMS");  // experiments: overrides cfg.streams
@@ -903,8 +990,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
     e->n_streams = ns == 0 ? 2 : (ns < 1 ? 1 : (ns > dptx_engine::MAX_STREAMS ? dptx_engine::MAX_STREAMS : ns));
   }
   e->max_w = max_w;
-  e->tok_tap_stride = (size_t)cfg->max_batch * ((size_t)max_h * max_w / 256 + 1) * D_VIT;
-  e->spec = build_spec(cfg->num_channels, cfg->dual_task != 0);
+  e->tok_tap_stride = (size_t)cfg->max_batch * ((size_t)max_h * max_w / 256 + 1) * (size_t)e->dv;
+  e->spec = build_spec(cfg->num_channels, cfg->dual_task != 0, e->backbone);
   size_t off = 0;
   for (size_t i = 0; i < e->spec.size(); ++i) {
     e->spec_index[e->spec[i].key] = i;
@@ -1035,7 +1122,7 @@ int dptx_enable_taps(dptx_handle h, int on) {
   if (on && !h->d_tok_taps) {
     DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
-    HIPCHK(h, hipMalloc((void**)&h->d_tok_taps, (size_t)13 * h->tok_tap_stride * 4));
+    HIPCHK(h, hipMalloc((void**)&h->d_tok_taps, (size_t)(h->depth + 1) * h->tok_tap_stride * 4));
   }
   h->taps_on = on != 0;
   return DPTX_OK;
@@ -1165,7 +1252,9 @@ int dptx_forward_info(dptx_handle h, int64_t* launches, double* algorithmic_macs
   if (!h) return DPTX_E_INVALID;
   if (launches) *launches = h->launches;
   if (algorithmic_macs)  // SURVEY.md 8d (dual: 69.96 shared + 2 x 57.67 per image pair)
-    *algorithmic_macs = h->cfg.dual_task ? 185.29e9 : (h->cfg.num_channels == 3 ? 127.624e9 : 127.615e9);
+    *algorithmic_macs = h->backbone == DPTX_BACKBONE_VITL16_384
+                            ? (h->cfg.num_channels == 3 ? 258.216e9 : 258.206e9)  // DPT-Large: 200.12 encoder + 58.08 decoder
+                            : (h->cfg.dual_task ? 185.29e9 : (h->cfg.num_channels == 3 ? 127.624e9 : 127.615e9));
   if (executed_macs) *executed_macs = h->exec_macs;
   return DPTX_OK;
 }

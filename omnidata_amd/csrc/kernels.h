@@ -111,6 +111,11 @@ hipError_t launch_readout_cls(int mode, const float* x, long long x_stride, cons
 // fp32 -> 16-bit (hi/lo planes in bf16x3 mode), n % 8 == 0
 hipError_t launch_cast_f32(int mode, const float* src, void* dst, size_t n, Planes pl, hipStream_t stream);
 
+// DPT-Large: x NCHW [B,3,H,W] (io type) -> 16x16 patches P[B*(H/16)*(W/16)][768], k = (c, ky, kx)
+hipError_t launch_patchify16(int mode, const void* x, int io, void* P, int B, int H, int W, Planes pl, hipStream_t stream);
+// G[(b,y,x)][(dy*k+dx)*C + c] -> Y[b][y*k+dy][x*k+dx][c]  (the re-layout half of a ConvTranspose2d with kernel == stride)
+hipError_t launch_depth_to_space(int mode, const void* G, void* Y, int B, int h, int w, int k, int C, Planes pl, hipStream_t stream);
+
 // generic 16-bit / fp32 -> fp32 copy for taps
 hipError_t launch_to_f32(int mode, const void* src, float* dst, size_t n, Planes pl, hipStream_t stream);
 

@@ -184,6 +184,69 @@ hipError_t launch_cast_f32(int mode, const float* src, void* dst, size_t n, Plan
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------ 16x16 patches (DPT-Large patch embedding)
+// timm PatchEmbed of vit_large_patch16_384 (vit.py:133 reaches it as patch_embed.proj): Conv2d(3, D, 16, stride 16).
+// x NCHW [B,3,H,W] (fp32 / bf16 / fp16) -> P[B*(H/16)*(W/16)][768] 16-bit with k = (c, ky, kx), the order of the flattened
+// conv weight, so the convolution is a dense GEMM P * W^T.  A thread owns 8 consecutive kx of one (patch, c, ky).
+template <int DT, int PL>
+__global__ __launch_bounds__(256) void patchify16_kernel(const void* __restrict__ x, int io, uint16_t* __restrict__ P, int B, int H,
+                                                         int W, long long plane) {
+  const int gh = H >> 4, gw = W >> 4;
+  const long long total = (long long)B * gh * gw * 96;  // 96 8-element vectors per patch row (3 * 16 * 16 / 8)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int v = (int)(i % 96);
+    const long long patch = i / 96;
+    const int px = (int)(patch % gw), py = (int)((patch / gw) % gh), b = (int)(patch / ((long long)gw * gh));
+    const int c = v >> 5, ky = (v >> 1) & 15, kx0 = (v & 1) * 8;
+    const long long src = (((long long)b * 3 + c) * H + py * 16 + ky) * W + px * 16 + kx0;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = io_load(x, src + e, io);
+    store8f<DT, PL>(P + patch * 768 + v * 8, plane, f);
+  }
+}
+hipError_t launch_patchify16(int mode, const void* x, int io, void* P, int B, int H, int W, Planes pl, hipStream_t stream) {
+  if (H % 16 != 0 || W % 16 != 0) return hipErrorInvalidValue;
+  const long long total = (long long)B * (H / 16) * (W / 16) * 96;
+  const int grid = (int)min((total + 255) / 256, (long long)16384);
+  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((patchify16_kernel<DT, PL>), dim3(grid), dim3(256), 0, stream, x, io, (uint16_t*)P, B, H,
+                                              W, pl.act));
+  return hipGetLastError();
+}
+
+// --------------------------------------------------- depth to space (ConvTranspose2d with kernel == stride)
+// act_postprocess1/2 of DPT-Large (vit.py:218-227, 241-250): ConvTranspose2d(C, C, k, stride k) has one tap per output
+// pixel, i.e. it is a GEMM [B*h*w, C] x [C, k*k*C] followed by this re-layout:
+//   G[(b, y, x)][(dy*k + dx)*C + c]  ->  Y[b][y*k + dy][x*k + dx][c]      (NHWC, 16-bit)
+template <int PL>
+__global__ __launch_bounds__(256) void depth_to_space_kernel(const uint16_t* __restrict__ G, uint16_t* __restrict__ Y, int B, int h,
+                                                             int w, int k, int C, long long plane) {
+  const int cvec = C >> 3;
+  const long long total = (long long)B * h * w * k * k * cvec;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int v = (int)(i % cvec);
+    long long r = i / cvec;
+    const int tap = (int)(r % (k * k));
+    r /= (k * k);
+    const int x = (int)(r % w), y = (int)((r / w) % h), b = (int)(r / ((long long)w * h));
+    const int dy = tap / k, dx = tap - dy * k;
+    const long long src = (((long long)b * h + y) * w + x) * ((long long)k * k * C) + (long long)tap * C + v * 8;
+    const long long dst = ((((long long)b * h * k + y * k + dy) * (w * k)) + x * k + dx) * C + v * 8;
+    *(uint4*)(Y + dst) = *(const uint4*)(G + src);
+    if (PL == 2) *(uint4*)(Y + plane + dst) = *(const uint4*)(G + plane + src);
+  }
+}
+hipError_t launch_depth_to_space(int mode, const void* G, void* Y, int B, int h, int w, int k, int C, Planes pl, hipStream_t stream) {
+  if (C % 8 != 0 || k < 1) return hipErrorInvalidValue;
+  const long long total = (long long)B * h * w * k * k * (C / 8);
+  const int grid = (int)min((total + 255) / 256, (long long)16384);
+  if (mode_is_x3(mode))
+    hipLaunchKernelGGL((depth_to_space_kernel<2>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)G, (uint16_t*)Y, B, h, w, k, C, pl.act);
+  else
+    hipLaunchKernelGGL((depth_to_space_kernel<1>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)G, (uint16_t*)Y, B, h, w, k, C, pl.act);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------ tap export
 template <int DT, int PL>
 __global__ void to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n, long long plane) {

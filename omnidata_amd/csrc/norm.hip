@@ -54,10 +54,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 hipError_t launch_layernorm(int mode, const float* x, const float* gamma, const float* beta, void* y, int M, int C,
                             float eps, Planes pl, hipStream_t stream) {
-  if (C != 768) return hipErrorInvalidValue;
+  if (C != 768 && C != 1024) return hipErrorInvalidValue;  // ViT-B (hybrid) / ViT-L widths: 3 or 4 float4 per lane
   dim3 grid((M + 3) / 4);
-  DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((layernorm_kernel<DT, PL, 3>), grid, dim3(256), 0, stream, x, gamma, beta,
-                                              (uint16_t*)y, M, C, eps, pl.act));
+  if (C == 768) {
+    DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((layernorm_kernel<DT, PL, 3>), grid, dim3(256), 0, stream, x, gamma, beta,
+                                                (uint16_t*)y, M, C, eps, pl.act));
+  } else {
+    DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((layernorm_kernel<DT, PL, 4>), grid, dim3(256), 0, stream, x, gamma, beta,
+                                                (uint16_t*)y, M, C, eps, pl.act));
+  }
   return hipGetLastError();
 }
 

@@ -32,12 +32,12 @@ def broadcast_blob(blob: Optional[torch.Tensor], nbytes: int, device: torch.devi
 
 
 def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dtype: str, device_index: int, src: int = 0,
-                            dual: bool = False, x3_groups=0):
+                            dual: bool = False, x3_groups=0, backbone: str = "vitb_rn50_384"):
     """Every rank gets an Engine with identical packed weights; only `src` runs the host-side
     fold/pack (state_dict_fn() is called on `src` only)."""
     from .engine import Engine
     eng = Engine(num_channels=num_channels, max_batch=max_batch, dtype=dtype, device_id=device_index, dual=dual,
-                 x3_groups=x3_groups)
+                 x3_groups=x3_groups, backbone=backbone)
     device = torch.device("cuda", device_index)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         eng.load_state_dict(state_dict_fn())

@@ -24,6 +24,8 @@ def groups_mask(names) -> int:
     if isinstance(names, str):
         names = [n for n in names.replace(",", "+").split("+") if n]
     return sum(GROUPS[n] for n in set(names))
+# include/dptx.h DPTX_BACKBONE_*
+BACKBONE_IDS = {"vitb_rn50_384": 0, "vitl16_384": 1}
 ERRORS = {0: "ok", -1: "invalid argument / call order", -2: "state_dict key error", -3: "HIP error",
           -4: "no device", -5: "allocation failed"}
 
@@ -32,7 +34,8 @@ class DptxConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("max_batch", C.c_int32), ("dtype", C.c_int32),
                 ("device_id", C.c_int32), ("non_negative", C.c_int32), ("ws_form", C.c_int32),
                 ("ws_eps", C.c_float), ("max_height", C.c_int32), ("max_width", C.c_int32),
-                ("dual_task", C.c_int32), ("streams", C.c_int32), ("x3_groups", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("dual_task", C.c_int32), ("streams", C.c_int32), ("x3_groups", C.c_int32), ("backbone", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 # (name, restype, argtypes) for every symbol declared in include/dptx.h
@@ -119,7 +122,8 @@ class Engine:
 
     def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "bf16",
                  device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8,
-                 max_hw: Tuple[int, int] = (384, 384), dual: bool = False, streams: int = 0, x3_groups=0):
+                 max_hw: Tuple[int, int] = (384, 384), dual: bool = False, streams: int = 0, x3_groups=0,
+                 backbone: str = "vitb_rn50_384"):
         self.lib = load_library()
         cfg = DptxConfig()
         self.lib.dptx_default_config(C.byref(cfg))
@@ -130,8 +134,10 @@ class Engine:
         cfg.dual_task = int(dual)
         cfg.streams = int(streams)
         cfg.x3_groups = groups_mask(x3_groups)  # dtype "mixed": groups that run 3 MFMAs per product (0 = all but the ViT blocks)
+        cfg.backbone = BACKBONE_IDS[backbone]
         self.cfg = cfg
         self.dtype = dtype
+        self.backbone = backbone
         self.h = _vp()
         rc = self.lib.dptx_create(C.byref(self.h), C.byref(cfg))
         if rc != 0:
@@ -190,7 +196,8 @@ class Engine:
     def _cache_meta(self) -> Dict[str, str]:
         c = self.cfg
         return {"format": "dptx-packed-v1", "library": self.lib.dptx_version().decode(), "dtype": self.dtype,
-                "num_channels": str(c.num_channels), "dual_task": str(c.dual_task), "ws_form": str(c.ws_form),
+                "num_channels": str(c.num_channels), "dual_task": str(c.dual_task), "backbone": self.backbone,
+                "ws_form": str(c.ws_form),
                 "ws_eps": repr(float(c.ws_eps)), "packed_bytes": str(self.packed_bytes)}
 
     def save_packed(self, path: str):

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .engine import Engine
 from .weights import (compose_dual_state_dict, dual_state_dict_spec, random_dual_state_dict, random_state_dict,
-                      read_checkpoint, state_dict_spec)
+                      read_checkpoint, state_dict_spec, BACKBONES)
 
 
 def _io_dtype(x: torch.Tensor) -> torch.dtype:
@@ -37,7 +37,8 @@ class BaseModel(nn.Module):
 
 
 class DPTDepthModel(BaseModel):
-    """Drop-in for ``DPTDepthModel(backbone='vitb_rn50_384', num_channels={1,3})``.
+    """Drop-in for ``DPTDepthModel(backbone={'vitb_rn50_384' | 'vitl16_384'}, num_channels={1,3})``
+    (DPT-Hybrid, the published omnidata configuration, and DPT-Large, demo.py:81 / dpt_depth.py:41-45).
 
     Extra keyword arguments (engine side): ``dtype`` in {'bf16','fp16','bf16x3','fp16x3','mixed'} -- MFMA operand /
     activation storage type.  'bf16' / 'fp16' are single-pass 16-bit arithmetic (fast; they deviate from the fp32
@@ -53,24 +54,25 @@ class DPTDepthModel(BaseModel):
                  channels_last: bool = False, use_bn: bool = False, dtype: str = "bf16",
                  max_batch: int = 32, init_seed: int = 0, x3_groups=0):
         super().__init__()
-        if backbone != "vitb_rn50_384":
+        if backbone not in BACKBONES:
             # blocks.py:42-44: unknown backbones print and assert
             print(f"Backbone '{backbone}' not implemented")
-            assert False, "only the DPT-Hybrid backbone 'vitb_rn50_384' is built for MI355X"
+            assert False, f"backbones built for MI355X: {BACKBONES} (DPT-Hybrid, DPT-Large)"
         if features != 256 or readout != "project" or use_bn:
             raise NotImplementedError("only features=256, readout='project', use_bn=False (the published "
                                       "omnidata DPT-Hybrid configuration) is supported")
         if num_channels not in (1, 3):
             raise ValueError("num_channels must be 1 (depth) or 3 (surface normals)")
         self.num_channels = num_channels
+        self.backbone = backbone
         self.non_negative = bool(non_negative)
         self.channels_last = channels_last  # accepted and, as in the reference (dpt_depth.py:68-69), a no-op
         self.engine_dtype = dtype
         self.x3_groups = x3_groups
         self.max_batch = max(1, min(int(max_batch), 48))  # engine limit; larger batches are chunked in forward()
         self.max_hw = (384, 384)  # arena is planned for this input size; grows on demand (forward_flex, vit.py:119)
-        init = random_state_dict(init_seed, num_channels)
-        for key, shape in state_dict_spec(num_channels).items():
+        init = random_state_dict(init_seed, num_channels, backbone=backbone)
+        for key, shape in state_dict_spec(num_channels, backbone=backbone).items():
             *mods, leaf = key.split(".")
             node = self
             for m in mods:
@@ -103,7 +105,7 @@ class DPTDepthModel(BaseModel):
                 self._engine.close()
             eng = Engine(num_channels=self.num_channels, max_batch=self._chunk(), dtype=self.engine_dtype,
                          device_id=key[0], non_negative=self.non_negative, max_hw=self.max_hw,
-                         x3_groups=self.x3_groups)
+                         x3_groups=self.x3_groups, backbone=self.backbone)
             eng.load_state_dict(super().state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine

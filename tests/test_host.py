@@ -52,7 +52,10 @@ def test_load_state_dict_strict_and_checkpoint_formats(tmp_path):
 
 def test_constructor_contract():
     with pytest.raises(AssertionError):
-        DPTDepthModel(backbone="vitl16_384")  # blocks.py:42-44 prints + asserts on unknown backbones
+        DPTDepthModel(backbone="vitb16_384")  # blocks.py:42-44 prints + asserts on backbones it does not know; vitb16 is not built here
+    large = DPTDepthModel(backbone="vitl16_384")  # DPT-Large (demo.py:81)
+    assert large.state_dict()["pretrained.model.blocks.23.mlp.fc1.weight"].shape == (4096, 1024)
+    assert "pretrained.act_postprocess1.4.weight" in large.state_dict()  # the ConvTranspose2d of reassemble stage 1
     with pytest.raises(NotImplementedError):
         DPTDepthModel(use_bn=True)
     with pytest.raises(ValueError):
