@@ -178,10 +178,15 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
 // partial[img][block][group]: no atomics, and the value of a record depends on the image's own rows only, so the
 // statistics are bit-identical run to run and at every batch size (needs rows-per-image % 32 == 0; the engine falls
 // back to the gn_stats kernel otherwise).
-template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1>
+//
+// ILV (gemm_ph_kernel, 256x256, 2 x 4 waves): a wave's 4 x 2 MFMA blocks are interleaved over the tile -- row block i of
+// wave row wm sits at tile row (i>>1)*128 + wm*64 + (i&1)*32, column block j of wave column wn at j*128 + wn*32 -- so that
+// the four 128-row half-tiles of a k-tile are needed one phase after the other.
+template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                          int tid, f32x16_t (&acc)[TM][TN]) {
   static_assert(SLABS == 1 || SLABS == TM, "one slab, or one per MFMA row tile");
+  static_assert(!ILV || (SLABS == TM && TM == 4 && TN == 2 && BM == 256 && BN == 256), "interleaved mapping: the phased kernel");
   constexpr int CT_PITCH = BN + 4;  // floats
   constexpr int CT_ROWS = BM / SLABS;
   constexpr int NCH = BN / 8;     // 8-column chunks per tile row
@@ -197,7 +202,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
     const int cpg = p.gn_cpg;  // channels per group: 2..32, a power of two
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + (wm * TM + i) * 32;  // first GEMM row of this wave's i-th 32-row block
+      // first GEMM row of this wave's i-th 32-row block
+      const int mb = m0 + (ILV ? (i >> 1) * 128 + wm * 64 + (i & 1) * 32 : (wm * TM + i) * 32);
       const int img = mb / p.gn_hw;
       const int blk = (mb - img * p.gn_hw) >> 5;
 #pragma unroll
@@ -209,7 +215,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         sq += __shfl_xor(sq, 32, 64);
         for (int o = 1; o < cpg; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
         if (lh == 0 && (lr & (cpg - 1)) == 0 && mb < p.M) {
-          const int g = (n0 + (wn * TN + j) * 32 + lr) / cpg;
+          const int g = (n0 + (ILV ? j * 128 + wn * 32 : (wn * TN + j) * 32) + lr) / cpg;
           float2* dst = (float2*)p.gn_part + ((long long)img * p.gn_blocks + blk) * 32 + g;
           *dst = make_float2(sm, sq);
         }
@@ -249,7 +255,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
 #pragma unroll
       for (int it = 0; it < GR; ++it) {
         const int row = rr + (gi * GR + it) * RPP;
-        int m = m0 + (SLABS == 1 ? row : (row >> 5) * (TM * 32) + s * 32 + (row & 31));
+        int m = m0 + (SLABS == 1 ? row
+                      : ILV      ? (s >> 1) * 128 + (row >> 5) * 64 + (s & 1) * 32 + (row & 31)
+                                 : (row >> 5) * (TM * 32) + s * 32 + (row & 31));
         ok[it] = m < p.M;
         m = ok[it] ? m : m0;  // any valid row: the loads stay in bounds, the store is masked
         int img = 0, pp = m;
@@ -301,7 +309,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ml = (SLABS == 1 ? wm * (TM * 32) + i * 32 : wm * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int nl = wn * (TN * 32) + j * 32 + lr;
+            const int nl = (ILV ? j * 128 + wn * 32 : wn * (TN * 32) + j * 32) + lr;
             ct[ml * CT_PITCH + nl] = acc[i][j][r];
           }
       }
@@ -718,6 +726,246 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 }
 
 // -------------------------------------------------------------------- register-staged kernel
+// ------------------------------------------------------------------- phased 256x256 kernel
+// Four phases per k-tile, two barriers per phase, the two wave groups (wm = 0 / 1) one barrier apart:
+//
+//     group 0:  | reads + 2 DMA pieces | 8 MFMAs | reads + 2 DMA | 8 MFMAs | ...
+//     group 1:            | 8 MFMAs | reads + 2 DMA pieces | 8 MFMAs | reads + ...
+//
+// so each SIMD always has one wave in its MFMA section while the other fetches its next fragments and issues its share of
+// the LDS-DMA (2 of the 64 one-KB pieces of a k-tile per wave and phase, instead of bursts of 12 / 4 per k-tile in
+// gemm_pp_kernel, whose fragment reads also sat in front of the MFMAs of the SAME wave).
+//
+// A k-tile is four 16-KB half-tiles: H0 = A rows 0..127, H1 = A rows 128..255, H2 = W rows 0..127, H3 = W rows 128..255.
+// Wave (wm, wn) owns rows [64 wm, +64) of H0 AND of H1, columns [32 wn, +32) of H2 AND of H3 (epilogue<ILV>), and its 4 x 2
+// accumulator blocks are visited as (top, j0), (top, j1), (bottom, j1), (bottom, j0): phase 0 reads H0 + H2, phase 1 H3,
+// phase 2 H1, phase 3 H2 again.  Tile t+1 is staged in the same order -- H0, H2, H3, H1 in phases 0..3 of tile t --
+// three (H0: four) phases before it is read, so the DMA of the two most recent steps stays in flight across the
+// barriers: every wave waits at the end of its MFMA section, group 0 with vmcnt(4), group 1 (whose wait comes one barrier
+// later) with vmcnt(2), and vmcnt(0) only in the last k-tile.  A half-tile buffer is re-staged at least two phases after
+// its last fragment read (H2: read in phase 3 of tile t-1, written in phase 1 of tile t).
+template <int DT, bool RELU_A>
+__global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
+  constexpr int SLABS = TM;
+  constexpr int HALF = 128 * 128, TILE_BYTES = 4 * HALF;  // bytes: one half-tile, one k-tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
+    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
+    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
+    if (mt >= tiles_m || l >= tm_per * tn_per) return;
+    m0 = mt * BM;
+    n0 = nt * BN;
+  }
+
+  // loader: a wave-instruction moves 8 rows x 128 B; lane (r8 = lane>>3, kc = lane&7) owns chunk kc of row lrow (and of
+  // row 64 + lrow) of every half-tile.  q = 2*h + z: half h, rows z*64 + lrow.
+  const int kc = lane & 7, lrow = wave * 8 + (lane >> 3);
+  const int sc = kc ^ ((lrow >> 1) & 7);
+  int a_iy0[4], a_ix0[4];
+  unsigned a_off[4], w_off[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + (q >> 1) * 128 + (q & 1) * 64 + lrow;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    int rem, ox;
+    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
+    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
+    a_iy0[q] = ok ? oy * p.stride - p.pad_t : -0x40000000;
+    a_ix0[q] = ox * p.stride - p.pad_l;
+    const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[q] * p.Win + a_ix0[q]) * p.a_pix_stride + sc * 8;
+    a_off[q] = (unsigned)(ok ? e * 2 : 0);
+    w_off[q] = (unsigned)(((long long)(n0 + (q >> 1) * 128 + (q & 1) * 64 + lrow) * p.ldw + sc * 8) * 2);
+  }
+  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
+
+  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k-tile being staged (wave-uniform)
+  const int ld_base = wave * 8 * 128;
+  // the two pieces of A half H (0 / 1) resp. W half H of the k-tile at (ky, kx, c0) into buffer BUF
+#define DPTX_PH_PIECE_A(BUF, H, Z)                                                                                 \
+  do {                                                                                                             \
+    char* d_ = smem + (BUF) * TILE_BYTES + (H) * HALF + ld_base + (Z) * 64 * 128;                                  \
+    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
+    const int iy = a_iy0[2 * (H) + (Z)] + ky, ix = a_ix0[2 * (H) + (Z)] + kx;                                      \
+    const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)d_, 16,               \
+                                             valid ? a_off[2 * (H) + (Z)] + tap_ : OOB, 0, 0, 0);                  \
+  } while (0)
+#define DPTX_PH_PIECE_W(BUF, H, Z)                                                                                 \
+  do {                                                                                                             \
+    char* d_ = smem + (BUF) * TILE_BYTES + (2 + (H)) * HALF + ld_base + (Z) * 64 * 128;                            \
+    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);                                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)d_, 16,               \
+                                             w_off[2 * (H) + (Z)] + wk_, 0, 0, 0);                                 \
+  } while (0)
+#define DPTX_PH_STAGE_A(BUF, H) do { DPTX_PH_PIECE_A(BUF, H, 0); DPTX_PH_PIECE_A(BUF, H, 1); } while (0)
+#define DPTX_PH_STAGE_W(BUF, H) do { DPTX_PH_PIECE_W(BUF, H, 0); DPTX_PH_PIECE_W(BUF, H, 1); } while (0)
+#define DPTX_PH_NEXT_TAP()                                                                                         \
+  do {                                                                                                             \
+    if (p.k_tap_fast) {                                                                                            \
+      if (++kx == p.ksz) { kx = 0; if (++ky == p.ksz) { ky = 0; c0 += BK; } }                                      \
+    } else {                                                                                                       \
+      c0 += BK;                                                                                                    \
+      if (c0 >= p.Cin) { c0 = 0; if (++kx == p.ksz) { kx = 0; ++ky; } }                                            \
+    }                                                                                                              \
+  } while (0)
+
+  // fragment reads: row r of a half-tile is 128 B, chunk c at ((c ^ ((r >> 1) & 7)) << 4); the swizzle term of all of a
+  // lane's rows is (lr >> 1) & 7 (the wave offsets are multiples of 32 rows)
+  const int sw = (lr >> 1) & 7;
+  const int a_rd = (wm * 64 + lr) * 128, b_rd = (wn * 32 + lr) * 128;
+  int ch[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ch[ks] = ((2 * ks + lh) ^ sw) << 4;
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  // prologue: all of tile 0
+  DPTX_PH_STAGE_A(0, 0);
+  DPTX_PH_STAGE_W(0, 0);
+  DPTX_PH_STAGE_W(0, 1);
+  DPTX_PH_STAGE_A(0, 1);
+  DPTX_PH_NEXT_TAP();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wm == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one barrier behind
+
+#define DPTX_PH_WAIT()                                                                                             \
+  do {                                                                                                             \
+    if (!stage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+    else if (wm == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                          \
+  } while (0)
+#define DPTX_PH_MMA(I0, J, BF, HOOK0, HOOK1)                                                                       \
+  do {                                                                                                             \
+    DPTX_PH_PRIO(1);                                                                                               \
+    acc[I0][J] = T16<DT>::mfma32(af[0][0], BF[0], acc[I0][J]);                                                     \
+    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][0], BF[0], acc[I0 + 1][J]);                                             \
+    HOOK0;                                                                                                         \
+    acc[I0][J] = T16<DT>::mfma32(af[0][1], BF[1], acc[I0][J]);                                                     \
+    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][1], BF[1], acc[I0 + 1][J]);                                             \
+    acc[I0][J] = T16<DT>::mfma32(af[0][2], BF[2], acc[I0][J]);                                                     \
+    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][2], BF[2], acc[I0 + 1][J]);                                             \
+    HOOK1;                                                                                                         \
+    acc[I0][J] = T16<DT>::mfma32(af[0][3], BF[3], acc[I0][J]);                                                     \
+    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][3], BF[3], acc[I0 + 1][J]);                                             \
+    DPTX_PH_PRIO(0);                                                                                               \
+  } while (0)
+
+#ifdef DPTX_PH_NOPRIO
+#define DPTX_PH_PRIO(X) do { } while (0)
+#else
+#define DPTX_PH_PRIO(X) __builtin_amdgcn_s_setprio(X)
+#endif
+// DPTX_PH_SPLIT: 0 both DMA pieces of a phase in the load section, 1 one there and one between the MFMAs, 2 both
+// between the MFMAs (the matrix pipe keeps executing while the wave is stuck in the DMA issue)
+#ifndef DPTX_PH_SPLIT
+#define DPTX_PH_SPLIT 0
+#endif
+#define DPTX_PH_L(KIND, BUF, H) do { if (stage) { if (DPTX_PH_SPLIT == 0) DPTX_PH_STAGE_##KIND(BUF, H); else if (DPTX_PH_SPLIT == 1) DPTX_PH_PIECE_##KIND(BUF, H, 0); } } while (0)
+#define DPTX_PH_M0(KIND, BUF, H) do { if (stage && DPTX_PH_SPLIT == 2) DPTX_PH_PIECE_##KIND(BUF, H, 0); } while (0)
+#define DPTX_PH_M1(KIND, BUF, H) do { if (stage && DPTX_PH_SPLIT >= 1) DPTX_PH_PIECE_##KIND(BUF, H, 1); } while (0)
+#ifdef DPTX_PH_STAGE_FIRST   // experiment: DMA pieces in front of the fragment reads
+#define DPTX_PH_LOADS(READS, STAGE) do { STAGE; READS; } while (0)
+#else
+#define DPTX_PH_LOADS(READS, STAGE) do { READS; STAGE; } while (0)
+#endif
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool stage = kt + 1 < nk;
+    const int cb = kt & 1, nb = cb ^ 1;
+    const char* t_ = smem + cb * TILE_BYTES;
+    u32x4_t af[2][4], b0[4], b1[4];
+    // ---- phase 0: (top, j0)
+    DPTX_PH_LOADS(
+        {
+          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const u32x4_t*)(t_ + 2 * HALF + b_rd + ch[ks]);
+          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {
+            af[0][ks] = *(const u32x4_t*)(t_ + a_rd + ch[ks]);
+            af[1][ks] = *(const u32x4_t*)(t_ + a_rd + 32 * 128 + ch[ks]);
+          }
+        },
+        { DPTX_PH_L(A, nb, 0); });
+    asm volatile("s_barrier" ::: "memory");
+    if (RELU_A) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { af[0][ks] = relu8(af[0][ks]); af[1][ks] = relu8(af[1][ks]); }
+    }
+    DPTX_PH_MMA(0, 0, b0, DPTX_PH_M0(A, nb, 0), DPTX_PH_M1(A, nb, 0));
+    DPTX_PH_WAIT();
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 1: (top, j1)
+    DPTX_PH_LOADS({ _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b1[ks] = *(const u32x4_t*)(t_ + 3 * HALF + b_rd + ch[ks]); },
+                  { DPTX_PH_L(W, nb, 0); });
+    asm volatile("s_barrier" ::: "memory");
+    DPTX_PH_MMA(0, 1, b1, DPTX_PH_M0(W, nb, 0), DPTX_PH_M1(W, nb, 0));
+    DPTX_PH_WAIT();
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 2: (bottom, j1)
+    DPTX_PH_LOADS(
+        {
+          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {
+            af[0][ks] = *(const u32x4_t*)(t_ + HALF + a_rd + ch[ks]);
+            af[1][ks] = *(const u32x4_t*)(t_ + HALF + a_rd + 32 * 128 + ch[ks]);
+          }
+        },
+        { DPTX_PH_L(W, nb, 1); });
+    asm volatile("s_barrier" ::: "memory");
+    if (RELU_A) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { af[0][ks] = relu8(af[0][ks]); af[1][ks] = relu8(af[1][ks]); }
+    }
+    DPTX_PH_MMA(2, 1, b1, DPTX_PH_M0(W, nb, 1), DPTX_PH_M1(W, nb, 1));
+    DPTX_PH_WAIT();
+    asm volatile("s_barrier" ::: "memory");
+    // ---- phase 3: (bottom, j0)
+    DPTX_PH_LOADS({ _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const u32x4_t*)(t_ + 2 * HALF + b_rd + ch[ks]); },
+                  { DPTX_PH_L(A, nb, 1); });
+    asm volatile("s_barrier" ::: "memory");
+    DPTX_PH_MMA(2, 0, b0, DPTX_PH_M0(A, nb, 1), DPTX_PH_M1(A, nb, 1));
+    if (stage) DPTX_PH_NEXT_TAP();
+    DPTX_PH_WAIT();
+    asm volatile("s_barrier" ::: "memory");
+  }
+  if (wm == 0) asm volatile("s_barrier" ::: "memory");  // group 0 catches up
+#undef DPTX_PH_MMA
+#undef DPTX_PH_WAIT
+#undef DPTX_PH_LOADS
+#undef DPTX_PH_PRIO
+#undef DPTX_PH_NEXT_TAP
+#undef DPTX_PH_STAGE_W
+#undef DPTX_PH_STAGE_A
+#undef DPTX_PH_PIECE_W
+#undef DPTX_PH_PIECE_A
+#undef DPTX_PH_L
+#undef DPTX_PH_M0
+#undef DPTX_PH_M1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS, true>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+#endif
+}
+
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_FP32>
 __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
@@ -920,6 +1168,20 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   if constexpr (DT != DT_FP8 && PL == 1 && BM == 256 && BN == 256) {
     static int pp = -1;  // ping-pong schedule of the two wave groups (gemm_pp_kernel); DPTX_PP=0: the lockstep loop (A/B runs)
     if (pp < 0) { const char* t = getenv("DPTX_PP"); pp = t ? atoi(t) : 1; }
+    if (pp == 2 && glds_ok) {
+      if (p.a_relu) {
+        auto k = gemm_ph_kernel<DT, true>;
+        static bool done = false;
+        if (!done) { set_smem_attr(k, smem); done = true; }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
+      } else {
+        auto k = gemm_ph_kernel<DT, false>;
+        static bool done = false;
+        if (!done) { set_smem_attr(k, smem); done = true; }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
+      }
+      return hipGetLastError();
+    }
     if (pp && glds_ok) {
       if (p.a_relu) {
         auto k = gemm_pp_kernel<DT, true>;

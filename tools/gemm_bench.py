@@ -12,7 +12,9 @@ from omnidata_amd.engine import DTYPES, load_library  # noqa: E402
 
 B = 32
 DENSE = [("vit.qkv", B * 577, 2304, 768), ("vit.proj", B * 577, 768, 768), ("vit.fc1", B * 577, 3072, 768),
-         ("vit.fc2", B * 577, 768, 3072), ("stem.gemm", B * 36864, 64, 192), ("patch.proj", B * 576, 768, 1024)]
+         ("vit.fc2", B * 577, 768, 3072), ("stem.gemm", B * 36864, 64, 192), ("patch.proj", B * 576, 768, 1024),
+         # calibration against the square-GEMM figures of the CDNA4 programming guide (not DPT shapes; --only cal.4096,...)
+         ("cal.4096", 4096, 4096, 4096), ("cal.8192", 8192, 8192, 8192)]
 # name, H, Cin, Cout, k, stride, pad, Ho
 CONV = [("rcu@96", 96, 256, 256, 3, 1, 1, 96), ("rcu@48", 48, 256, 256, 3, 1, 1, 48), ("rcu@24", 24, 256, 256, 3, 1, 1, 24),
         ("rcu@12", 12, 256, 256, 3, 1, 1, 12), ("head.0", 192, 256, 128, 3, 1, 1, 192), ("head.2", 384, 128, 32, 3, 1, 1, 384),
@@ -62,7 +64,7 @@ def main():
     # the ViT GEMMs run with the epilogue the engine gives them: fc1 bias + GELU; proj / fc2 bias + in-place fp32 residual
     EPI = {"vit.fc1": (2, False), "vit.proj": (0, True), "vit.fc2": (0, True)}
     for name, M, N, K in DENSE:
-        if (only and name not in only) or fp8:
+        if (only and name not in only) or fp8 or (name.startswith("cal.") and not only):
             continue
         act, inplace32 = EPI.get(name, (0, False))
         A = torch.randn(M, K, device="cuda").to(tdt)
