@@ -566,6 +566,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
 #endif
 }
 
+// Quarter-step software pipeline of the fragment reads for the 128x64 wave tile (TM = 4, TN = 2) of the 256x256 kernels:
+// the six ds_read_b128 of k-step q+1 are in flight under the eight MFMAs of k-step q (two fragment sets = 48 registers,
+// what mma_tile's HK = 2 grouping holds as well), so only the first read of a k-tile is exposed -- and pp_read can issue
+// that one before the barrier in front of the MFMA slot.
+struct PpFrags { u32x4_t a[4], b[2]; };
+__device__ __forceinline__ void pp_read(PpFrags& f, const char* sa, const char* sb, int wm, int wn, int lr, int lh, int ks) {
+  const int chunk = 2 * ks + lh;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wm * 128 + i * 32 + lr;
+    f.a[i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wn * 64 + j * 32 + lr;
+    f.b[j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  }
+}
+template <int DT, bool RELU_A>
+__device__ __forceinline__ void pp_mma(PpFrags& f, f32x16_t (&acc)[4][2]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (RELU_A) f.a[i] = relu8(f.a[i]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], acc[i][j]);
+  }
+}
+// k-steps 0..3 of one k-tile; f0 already holds (or has in flight) k-step 0
+template <int DT, bool RELU_A>
+__device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char* sa, const char* sb, int wm, int wn, int lr, int lh,
+                                            f32x16_t (&acc)[4][2]) {
+  pp_read(f1, sa, sb, wm, wn, lr, lh, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_mma<DT, RELU_A>(f0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_read(f0, sa, sb, wm, wn, lr, lh, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_mma<DT, RELU_A>(f1, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_read(f1, sa, sb, wm, wn, lr, lh, 3);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_mma<DT, RELU_A>(f0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_mma<DT, RELU_A>(f1, acc);
+}
+
 // ------------------------------------------------------------------- ping-pong 256x256 kernel
 // The k-loop trace of gemm_glds_kernel (tools/gpu/gemm_trace.py, profiles/r02_gemm_trace.txt) shows what bounds the
 // 256x256 tile: an iteration is 4100 cycles for 2048 cycles of MFMA work per SIMD, because the eight waves run in
@@ -687,6 +733,50 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   __syncthreads();
   // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
   // that hipcc resolves with copies: 500 spilled registers)
+#ifndef DPTX_PP_NOPIPE
+  PpFrags f0, f1;
+  if (wm == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      DPTX_STAMP(0);
+      const char* sa = smem + (kt & 1) * STAGE_BYTES;
+#ifdef DPTX_PP_PREREAD
+      pp_read(f0, sa, sa + B_BASE, 0, wn, lr, lh, 0);            // slot 1: the first fragments of tile kt, then the DMA
+#endif
+      if (kt + 1 < nk) DPTX_PP_ISSUE((kt + 1) & 1);
+      DPTX_STAMP(1);
+      asm volatile("s_barrier" ::: "memory");
+      DPTX_STAMP(2);
+#ifndef DPTX_PP_PREREAD
+      pp_read(f0, sa, sa + B_BASE, 0, wn, lr, lh, 0);
+#endif
+      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sa + B_BASE, 0, wn, lr, lh, acc);  // slot 2
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of slot 1 has landed before group 1 reads it
+      DPTX_STAMP(3);
+      asm volatile("s_barrier" ::: "memory");
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      DPTX_STAMP(0);
+      const char* sa = smem + (kt & 1) * STAGE_BYTES;            // slot 1
+      pp_read(f0, sa, sa + B_BASE, 1, wn, lr, lh, 0);
+      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sa + B_BASE, 1, wn, lr, lh, acc);
+#ifndef DPTX_PP_PREREAD
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of the previous slot 2 (A rows 0..127 of THIS
+#endif                                                           // tile) has landed before group 0 reads it in slot 2
+      DPTX_STAMP(1);
+      asm volatile("s_barrier" ::: "memory");
+      DPTX_STAMP(2);
+      if (kt + 1 < nk) DPTX_PP_ISSUE((kt + 1) & 1);              // slot 2
+#ifdef DPTX_PP_PREREAD
+      // experiment: group 0 reads these rows (A rows 0..127 of tile kt+1) right after the next barrier, in front of its
+      // own DMA, so they are drained here (exposes the DMA latency whenever it exceeds group 0's MFMA slot)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      DPTX_STAMP(3);
+      asm volatile("s_barrier" ::: "memory");
+    }
+  }
+#else
   if (wm == 0) {
     for (int kt = 0; kt < nk; ++kt) {
       DPTX_STAMP(0);
@@ -714,6 +804,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       asm volatile("s_barrier" ::: "memory");
     }
   }
+#endif
 #ifdef DPTX_TRACE
   if (tr && wave == 0) { trp[62 * 4 + 2] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 3] = (long long)wall_clock64(); }
 #endif
@@ -1249,9 +1340,9 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   }
   // 256x256 (8 waves, 1 block/CU; 16-bit modes: the ping-pong kernel): half the DMA issues and 3/4 of the LDS reads per MFMA
   // of the 128x128 tile, but no second block to hide prologue/epilogue and a coarser tail.  Chosen when its estimated
-  // efficiency wins: fill of the last round of CUs (256 slots) x 1.07 (the measured per-tile advantage at K >= 512,
-  // profiles/r02_experiments.md) against the fill of the 128x128 grid (512 slots).  That picks it for fc2, qkv, proj,
-  // patch-embed and the 3x3 convs at 1/4 resolution and keeps 128x128 for fc1 (85.6 % vs 97 % fill) and the small maps.
+  // efficiency wins: fill of the last round of CUs (256 slots) x 1.25 (the measured per-tile advantage at K >= 512 with the
+  // pipelined fragment reads, profiles/r02_experiments.md) against the fill of the 128x128 grid (512 slots).  That picks
+  // it for the ViT GEMMs, patch-embed and the 3x3 convs at 1/4 resolution and keeps 128x128 for the small maps.
   if constexpr (PL == 1) {
     const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
     static int min_k = -1;  // DPTX_T256_MINK: shortest K that takes the 256x256 tile (experiments)
@@ -1260,7 +1351,9 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
       const long long t256 = m256 * (p.N / 256), r256 = (t256 + 255) / 256;
       const long long t128 = m128 * (p.N / 128), r128 = (t128 + 511) / 512;
       const double fill256 = (double)t256 / (double)(r256 * 256), fill128 = (double)t128 / (double)(r128 * 512);
-      if (t256 >= 200 && fill256 * 1.07 >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
+      static double adv = -1.0;  // DPTX_T256_ADV: per-tile advantage of the 256x256 kernel assumed by the rule (experiments)
+      if (adv < 0.0) { const char* t = getenv("DPTX_T256_ADV"); adv = t ? atof(t) : 1.25; }
+      if (t256 >= 200 && fill256 * adv >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
     }
   }
   if constexpr (PL == 2) {
