@@ -571,11 +571,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
 // what mma_tile's HK = 2 grouping holds as well), so only the first read of a k-tile is exposed -- and pp_read can issue
 // that one before the barrier in front of the MFMA slot.
 struct PpFrags { u32x4_t a[4], b[2]; };
-__device__ __forceinline__ void pp_read(PpFrags& f, const char* sa, const char* sb, int wm, int wn, int lr, int lh, int ks) {
+// sa: the wave group's 128-row A tile, sb: the 256-row W tile
+__device__ __forceinline__ void pp_read(PpFrags& f, const char* sa, const char* sb, int wn, int lr, int lh, int ks) {
   const int chunk = 2 * ks + lh;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = wm * 128 + i * 32 + lr;
+    const int row = i * 32 + lr;
     f.a[i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
   }
 #pragma unroll
@@ -595,17 +596,17 @@ __device__ __forceinline__ void pp_mma(PpFrags& f, f32x16_t (&acc)[4][2]) {
 }
 // k-steps 0..3 of one k-tile; f0 already holds (or has in flight) k-step 0
 template <int DT, bool RELU_A>
-__device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char* sa, const char* sb, int wm, int wn, int lr, int lh,
+__device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char* sa, const char* sb, int wn, int lr, int lh,
                                             f32x16_t (&acc)[4][2]) {
-  pp_read(f1, sa, sb, wm, wn, lr, lh, 1);
+  pp_read(f1, sa, sb, wn, lr, lh, 1);
   __builtin_amdgcn_sched_barrier(0);
   pp_mma<DT, RELU_A>(f0, acc);
   __builtin_amdgcn_sched_barrier(0);
-  pp_read(f0, sa, sb, wm, wn, lr, lh, 2);
+  pp_read(f0, sa, sb, wn, lr, lh, 2);
   __builtin_amdgcn_sched_barrier(0);
   pp_mma<DT, RELU_A>(f1, acc);
   __builtin_amdgcn_sched_barrier(0);
-  pp_read(f1, sa, sb, wm, wn, lr, lh, 3);
+  pp_read(f1, sa, sb, wn, lr, lh, 3);
   __builtin_amdgcn_sched_barrier(0);
   pp_mma<DT, RELU_A>(f0, acc);
   __builtin_amdgcn_sched_barrier(0);
@@ -628,18 +629,27 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 // group 1 reads -- A rows 128..255 and all of W -- is issued by GROUP 0 one full slot earlier (12 instructions per wave),
 // and group 1 issues only A rows 0..127 (4 instructions), which group 0 reads a full iteration later.  Every wave drains
 // its own DMA (vmcnt(0)) at the end of its MFMA slot, i.e. before the barrier in front of the first reader.
-template <int DT, bool RELU_A>
+// A3: three LDS buffers for A rows 128..255 (the pieces group 0 issues and group 1 reads first), 144 KB in all: they are
+// issued TWO tiles ahead, after the W pieces of the next tile, and group 0's wait at the end of its MFMA slot is
+// vmcnt(4) -- the W pieces (L2-resident, quick) must have landed, the four A pieces (streamed from HBM / far L2, the ones
+// the convolutions were seen waiting for) get one more iteration.
+template <int DT, bool RELU_A, bool A3>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, HK = 2, PL = 1;
+  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
   constexpr int SLABS = TM;
-  constexpr int B_BASE = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+  constexpr int HALF = 128 * 128;  // bytes of a 128-row operand tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // group = wm
   const int lr = lane & 31, lh = lane >> 5;
+  // LDS map.  !A3: stage b = [A rows 0..127 | A rows 128..255 | W rows 0..255] at b * 64 KB.
+  //            A3: W x 2 at 0, A rows 0..127 x 2 at 64 KB, A rows 128..255 x 3 at 96 KB.
+  auto w_ptr = [&](int b) -> char* { return smem + (A3 ? b * 2 * HALF : b * 4 * HALF + 2 * HALF); };
+  auto alo_ptr = [&](int b) -> char* { return smem + (A3 ? 4 * HALF + b * HALF : b * 4 * HALF); };
+  auto ahi_ptr = [&](int h) -> char* { return smem + (A3 ? 6 * HALF + h * HALF : h * 4 * HALF + HALF); };
 
   const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
   int m0, n0;
@@ -681,32 +691,40 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
 
-  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k-tile this group loads next (wave-uniform)
+  // tap / channel offset (wave-uniform) of the k-tile whose A rows this group loads next, and (group 0) whose W rows
+  int ky = 0, kx = 0, c0 = 0, kyw = 0, kxw = 0, c0w = 0;
   const int wq = wave & 3;     // wave inside its group: rows 8*wq .. 8*wq+7 of every 32-row pass
-#define DPTX_PP_ISSUE(BUF)                                                                                         \
+#define DPTX_PP_NEXT(KY, KX, C0)                                                                                   \
   do {                                                                                                             \
-    char* st_ = smem + (BUF) * STAGE_BYTES;                                                                        \
+    if (p.k_tap_fast) {                                                                                            \
+      if (++KX == p.ksz) { KX = 0; if (++KY == p.ksz) { KY = 0; C0 += BK; } }                                      \
+    } else {                                                                                                       \
+      C0 += BK;                                                                                                    \
+      if (C0 >= p.Cin) { C0 = 0; if (++KX == p.ksz) { KX = 0; ++KY; } }                                            \
+    }                                                                                                              \
+  } while (0)
+  // this group's four A pieces of the tile at (ky, kx, c0) into the 128-row tile at DST; advances the tap
+#define DPTX_PP_ISSUE_A(DST)                                                                                       \
+  do {                                                                                                             \
+    char* d_ = (DST) + wq * 1024;                                                                                  \
     const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
       const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
       const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                    \
-          rsrcA, (__attribute__((address_space(3))) void*)(st_ + (a_row0 + 32 * i) * 128 + wq * 1024), 16,          \
-          valid ? a_off[i] + tap_ : OOB, 0, 0, 0);                                                                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(d_ + 32 * i * 128), 16, \
+                                               valid ? a_off[i] + tap_ : OOB, 0, 0, 0);                            \
     }                                                                                                              \
-    if (wm == 0) {                                                                                                 \
-      const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);                                     \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
-            rsrcW, (__attribute__((address_space(3))) void*)(st_ + B_BASE + 32 * j * 128 + wq * 1024), 16,          \
-            w_off[j] + wk_, 0, 0, 0);                                                                              \
-    }                                                                                                              \
-    if (p.k_tap_fast) {                                                                                            \
-      if (++kx == p.ksz) { kx = 0; if (++ky == p.ksz) { ky = 0; c0 += BK; } }                                      \
-    } else {                                                                                                       \
-      c0 += BK;                                                                                                    \
-      if (c0 >= p.Cin) { c0 = 0; if (++kx == p.ksz) { kx = 0; ++ky; } }                                            \
-    }                                                                                                              \
+    DPTX_PP_NEXT(ky, kx, c0);                                                                                      \
+  } while (0)
+  // the eight W pieces of the tile at (kyw, kxw, c0w) into the 256-row tile at DST; advances that tap
+#define DPTX_PP_ISSUE_W(DST)                                                                                       \
+  do {                                                                                                             \
+    char* d_ = (DST) + wq * 1024;                                                                                  \
+    const unsigned wk_ = (unsigned)((((kyw * p.ksz + kxw) * p.Cin) + c0w) * 2);                                    \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(d_ + 32 * j * 128), 16, \
+                                               w_off[j] + wk_, 0, 0, 0);                                           \
+    DPTX_PP_NEXT(kyw, kxw, c0w);                                                                                   \
   } while (0)
 
   f32x16_t acc[TM][TN];
@@ -728,95 +746,72 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #ifdef DPTX_TRACE
   if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
 #endif
-  DPTX_PP_ISSUE(0);
+  // prologue: tile 0 (A3: also A rows 128..255 of tile 1)
+  if (wm == 0) {
+    DPTX_PP_ISSUE_W(w_ptr(0));
+    DPTX_PP_ISSUE_A(ahi_ptr(0));
+    if (A3 && nk > 1) DPTX_PP_ISSUE_A(ahi_ptr(1));
+  } else {
+    DPTX_PP_ISSUE_A(alo_ptr(0));
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
   // that hipcc resolves with copies: 500 spilled registers)
-#ifndef DPTX_PP_NOPIPE
   PpFrags f0, f1;
   if (wm == 0) {
+    int h_wr = 2;  // A3: buffer of A rows 128..255 of tile kt + 2
     for (int kt = 0; kt < nk; ++kt) {
       DPTX_STAMP(0);
-      const char* sa = smem + (kt & 1) * STAGE_BYTES;
-#ifdef DPTX_PP_PREREAD
-      pp_read(f0, sa, sa + B_BASE, 0, wn, lr, lh, 0);            // slot 1: the first fragments of tile kt, then the DMA
-#endif
-      if (kt + 1 < nk) DPTX_PP_ISSUE((kt + 1) & 1);
+      // slot 1: the DMA.  !A3: W and A rows 128..255 of tile kt+1.  A3: W of tile kt+1, then A rows 128..255 of tile kt+2.
+      if (kt + 1 < nk) DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
+      const bool more_a = A3 ? kt + 2 < nk : kt + 1 < nk;
+      if (more_a) DPTX_PP_ISSUE_A(ahi_ptr(A3 ? h_wr : (kt + 1) & 1));
+      if (A3) h_wr = h_wr == 2 ? 0 : h_wr + 1;
       DPTX_STAMP(1);
       asm volatile("s_barrier" ::: "memory");
       DPTX_STAMP(2);
-#ifndef DPTX_PP_PREREAD
-      pp_read(f0, sa, sa + B_BASE, 0, wn, lr, lh, 0);
-#endif
-      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sa + B_BASE, 0, wn, lr, lh, acc);  // slot 2
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of slot 1 has landed before group 1 reads it
+      const char* sa = alo_ptr(kt & 1);                          // slot 2
+      const char* sb = w_ptr(kt & 1);
+      pp_read(f0, sa, sb, wn, lr, lh, 0);
+      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
+      // what group 1 reads in its next slot has landed: everything (!A3), everything but the newest four pieces (A3)
+      if (A3 && more_a) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       DPTX_STAMP(3);
       asm volatile("s_barrier" ::: "memory");
     }
   } else {
+    int h_rd = 0;
     for (int kt = 0; kt < nk; ++kt) {
       DPTX_STAMP(0);
-      const char* sa = smem + (kt & 1) * STAGE_BYTES;            // slot 1
-      pp_read(f0, sa, sa + B_BASE, 1, wn, lr, lh, 0);
-      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sa + B_BASE, 1, wn, lr, lh, acc);
-#ifndef DPTX_PP_PREREAD
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of the previous slot 2 (A rows 0..127 of THIS
-#endif                                                           // tile) has landed before group 0 reads it in slot 2
-      DPTX_STAMP(1);
-      asm volatile("s_barrier" ::: "memory");
-      DPTX_STAMP(2);
-      if (kt + 1 < nk) DPTX_PP_ISSUE((kt + 1) & 1);              // slot 2
-#ifdef DPTX_PP_PREREAD
-      // experiment: group 0 reads these rows (A rows 0..127 of tile kt+1) right after the next barrier, in front of its
-      // own DMA, so they are drained here (exposes the DMA latency whenever it exceeds group 0's MFMA slot)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-      DPTX_STAMP(3);
-      asm volatile("s_barrier" ::: "memory");
-    }
-  }
-#else
-  if (wm == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      DPTX_STAMP(0);
-      if (kt + 1 < nk) DPTX_PP_ISSUE((kt + 1) & 1);              // slot 1
-      DPTX_STAMP(1);
-      asm volatile("s_barrier" ::: "memory");
-      DPTX_STAMP(2);
-      const char* sa = smem + (kt & 1) * STAGE_BYTES;            // slot 2
-      mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, 0, 0, 0, wn, lr, lh, acc);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of slot 1 has landed before group 1 reads it
-      DPTX_STAMP(3);
-      asm volatile("s_barrier" ::: "memory");
-    }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      DPTX_STAMP(0);
-      const char* sa = smem + (kt & 1) * STAGE_BYTES;            // slot 1
-      mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, 0, 0, 1, wn, lr, lh, acc);
+      const char* sa = ahi_ptr(A3 ? h_rd : kt & 1);              // slot 1
+      const char* sb = w_ptr(kt & 1);
+      if (A3) h_rd = h_rd == 2 ? 0 : h_rd + 1;
+      pp_read(f0, sa, sb, wn, lr, lh, 0);
+      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of the previous slot 2 (A rows 0..127 of THIS
       DPTX_STAMP(1);                                             // tile) has landed before group 0 reads it in slot 2
       asm volatile("s_barrier" ::: "memory");
       DPTX_STAMP(2);
-      if (kt + 1 < nk) DPTX_PP_ISSUE((kt + 1) & 1);              // slot 2
+      if (kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
       DPTX_STAMP(3);
       asm volatile("s_barrier" ::: "memory");
     }
   }
-#endif
 #ifdef DPTX_TRACE
   if (tr && wave == 0) { trp[62 * 4 + 2] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 3] = (long long)wall_clock64(); }
 #endif
 #undef DPTX_STAMP
-#undef DPTX_PP_ISSUE
+#undef DPTX_PP_ISSUE_W
+#undef DPTX_PP_ISSUE_A
+#undef DPTX_PP_NEXT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
 }
 
-// -------------------------------------------------------------------- register-staged kernel
 // ------------------------------------------------------------------- phased 256x256 kernel
 // Four phases per k-tile, two barriers per phase, the two wave groups (wm = 0 / 1) one barrier apart:
 //
@@ -1274,16 +1269,19 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       return hipGetLastError();
     }
     if (pp && glds_ok) {
-      if (p.a_relu) {
-        auto k = gemm_pp_kernel<DT, true>;
+      // pp == 3: three LDS buffers for A rows 128..255 (144 KB)
+      auto go = [&](auto k, size_t bytes) {
         static bool done = false;
-        if (!done) { set_smem_attr(k, smem); done = true; }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
+        if (!done) { set_smem_attr(k, bytes); done = true; }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), bytes, stream, q);
+      };
+      constexpr size_t smem3 = 144 * 1024;
+      if (pp == 3) {
+        if (p.a_relu) go(gemm_pp_kernel<DT, true, true>, smem3);
+        else go(gemm_pp_kernel<DT, false, true>, smem3);
       } else {
-        auto k = gemm_pp_kernel<DT, false>;
-        static bool done = false;
-        if (!done) { set_smem_attr(k, smem); done = true; }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
+        if (p.a_relu) go(gemm_pp_kernel<DT, true, false>, smem);
+        else go(gemm_pp_kernel<DT, false, false>, smem);
       }
       return hipGetLastError();
     }
