@@ -25,7 +25,9 @@ def main(argv=None):
     parser.add_argument("--output_path", dest="output_path", help="path to where output image should be stored")
     parser.add_argument("--weights", default=None, help="checkpoint path (default ./pretrained_models/omnidata_dpt_<task>_v2.ckpt)")
     parser.add_argument("--random-weights", type=int, default=None, metavar="SEED", help="seeded synthetic weights (offline)")
-    parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "bf16x3"])
+    parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "bf16x3", "fp16x3", "mixed", "fp8"])
+    parser.add_argument("--backbone", default="vitb_rn50_384", choices=["vitb_rn50_384", "vitl16_384"],
+                        help="vitb_rn50_384 = DPT-Hybrid (the v2 checkpoints); vitl16_384 = DPT-Large (demo.py:81, the v1 depth model)")
     args = parser.parse_args(argv)
 
     if args.task not in ("normal", "depth"):
@@ -45,7 +47,10 @@ def main(argv=None):
     weights = args.weights
     if weights is None and args.random_weights is None:
         weights = "./pretrained_models/" + ("omnidata_dpt_normal_v2.ckpt" if args.task == "normal" else "omnidata_dpt_depth_v2.ckpt")
-    model = build_model(args.task, weights=weights, random_weights=args.random_weights, dtype=args.dtype, max_batch=1)
+        if args.backbone == "vitl16_384" and args.task == "depth":
+            weights = "./pretrained_models/omnidata_dpt_depth_v1.ckpt"  # the DPT-Large depth model (demo.py:80-81)
+    model = build_model(args.task, weights=weights, random_weights=args.random_weights, dtype=args.dtype, max_batch=1,
+                        backbone=args.backbone)
     model.to(device)
 
     def save_outputs(img_path, output_file_name):

@@ -232,12 +232,12 @@ class DPTDualTaskModel(nn.Module):
 
 
 def build_model(task: str = "normal", weights: Optional[str] = None, random_weights: Optional[int] = None,
-                **kw) -> DPTDepthModel:
-    """normal -> 3 channels, depth -> 1 channel (demo.py:63,82)."""
+                backbone: str = "vitb_rn50_384", **kw) -> DPTDepthModel:
+    """normal -> 3 channels, depth -> 1 channel (demo.py:63,82); backbone 'vitl16_384' = DPT-Large (demo.py:81)."""
     if task not in ("normal", "depth"):
         raise ValueError("task should be one of the following: normal, depth")
     C = 3 if task == "normal" else 1
-    model = DPTDepthModel(backbone="vitb_rn50_384", num_channels=C,
+    model = DPTDepthModel(backbone=backbone, num_channels=C,
                           init_seed=0 if random_weights is None else random_weights, **kw)
     if weights is not None:
         model.load_state_dict(read_checkpoint(weights))

@@ -40,6 +40,11 @@ def test_demo_cli_writes_reference_file_names(tmp_path):
     r = _run([os.path.join(ROOT, "demo.py"), "--task", "normal", "--img_path", str(src / "test1.png"), "--output_path",
               str(tmp_path / "o2"), "--random-weights", "1", "--dtype", "fp16"])
     assert r.returncode == 0 and (tmp_path / "o2" / "test1_normal.png").exists()
+    # DPT-Large (demo.py:81) in the parity mode
+    r = _run([os.path.join(ROOT, "demo.py"), "--task", "depth", "--img_path", str(src / "test1.png"), "--output_path",
+              str(tmp_path / "o3"), "--random-weights", "2", "--backbone", "vitl16_384", "--dtype", "mixed"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert Image.open(tmp_path / "o3" / "test1_depth.png").size == (512, 512)
 
 
 def test_hub_model_and_batch_sizes():
