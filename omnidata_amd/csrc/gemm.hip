@@ -184,7 +184,9 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
 // the four 128-row half-tiles of a k-tile are needed one phase after the other.
 template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
-                                         int tid, f32x16_t (&acc)[TM][TN]) {
+                                         int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0) {
+  // row_pitch != 0 (gemm_halo_kernel): the tile is 8 image rows x 32 pixels -- tile row R is GEMM row
+  // m0 + (R >> 5) * row_pitch + (R & 31)
   static_assert(SLABS == 1 || SLABS == TM, "one slab, or one per MFMA row tile");
   static_assert(!ILV || (SLABS == TM && TM == 4 && TN == 2 && BM == 256 && BN == 256), "interleaved mapping: the phased kernel");
   constexpr int CT_PITCH = BN + 4;  // floats
@@ -255,9 +257,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
 #pragma unroll
       for (int it = 0; it < GR; ++it) {
         const int row = rr + (gi * GR + it) * RPP;
-        int m = m0 + (SLABS == 1 ? row
-                      : ILV      ? (s >> 1) * 128 + (row >> 5) * 64 + (s & 1) * 32 + (row & 31)
-                                 : (row >> 5) * (TM * 32) + s * 32 + (row & 31));
+        int R = SLABS == 1 ? row
+                : ILV      ? (s >> 1) * 128 + (row >> 5) * 64 + (s & 1) * 32 + (row & 31)
+                           : (row >> 5) * (TM * 32) + s * 32 + (row & 31);
+        if (row_pitch) R = (R >> 5) * row_pitch + (R & 31);
+        int m = m0 + R;
         ok[it] = m < p.M;
         m = ok[it] ? m : m0;  // any valid row: the loads stay in bounds, the store is masked
         int img = 0, pp = m;
@@ -812,6 +816,190 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------- halo-resident 3x3 convolution
+// 3x3 / stride 1 / pad 1 convolutions on maps whose width is a multiple of 32 and height a multiple of 8 (the 1/4- and
+// 1/2-resolution maps of the decoder).  The implicit GEMM above fetches every input pixel nine times, once per tap, as part
+// of nine different A tiles; here a block owns 8 rows x 32 pixels of ONE image and 256 output channels, keeps the 10 x 34
+// input halo of a 64-channel chunk LDS-resident (43.5 KB) and runs the nine taps out of it: per 64-channel chunk the block
+// moves 43.5 KB of A and 9 x 32 KB of W through the LDS-DMA path instead of 9 x 64 KB (1.7x fewer bytes per flop).
+//
+// k order: chunk-major, taps inside a chunk = GemmParams::k_tap_fast, which launch_gemm forces for every shape this
+// kernel accepts, so that the result is bit-identical to the implicit-GEMM kernels' (small batches fall back to them).
+//
+// Same wave layout and ping-pong schedule as gemm_pp_kernel (group = 4 output rows x 32 pixels x 256 channels); group 0
+// issues the eight W pieces of the next (tap, chunk), group 1 the halo of the NEXT chunk, two of its 43 pieces per wave
+// and tap, which therefore have most of a chunk to land.
+template <int DT, bool RELU_A>
+__global__ __launch_bounds__(512, 2) void gemm_halo_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
+  constexpr int SLABS = TM;
+  constexpr int HC = 34, HPIX = 10 * HC, HPIECES = (HPIX + 7) / 8;  // 340 halo pixels in 43 pieces of 8 rows
+  constexpr int W_BYTES = 256 * 128, HALO_BYTES = 44 * 1024;        // 344 rows x 128 B = 44032 <= 45056
+  constexpr int HSLOTS = (HPIECES + 3) / 4;                         // pieces per wave of group 1: 11
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // W x 2 | halo x 2 = 152 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, wq = wave & 3;
+  const int lr = lane & 31, lh = lane >> 5;
+  auto w_ptr = [&](int b) -> char* { return smem + b * W_BYTES; };
+  auto h_ptr = [&](int b) -> char* { return smem + 2 * W_BYTES + b * HALO_BYTES; };
+
+  const int tx_n = p.Win >> 5, tpi = tx_n * (p.Hin >> 3);
+  const int tiles_n = p.N / BN, tiles_m = (p.M / p.a_rpi) * tpi;
+  int img, y0, x0, n0;
+  {
+    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
+    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
+    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
+    if (mt >= tiles_m || l >= tm_per * tn_per) return;
+    img = mt / tpi;
+    const int r = mt - img * tpi, ty = r / tx_n;
+    y0 = ty * 8;
+    x0 = (r - ty * tx_n) * 32;
+    n0 = nt * BN;
+  }
+  const int m_base = (img * p.Hin + y0) * p.Win + x0;
+
+  // loader offsets, one array for both roles (the groups never meet in this code):
+  //   group 1, wave wq: halo pieces id = 4 s + wq (s = 0..10); a piece is 8 halo pixels x 128 B, lane (lane>>3, lane&7)
+  //     owns chunk kc of halo pixel hp = 8 id + (lane >> 3); pixels outside the image (and the 4 rows past 339) read zeros
+  //   group 0: W rows r0 + 32 j (j = 0..7) of the 256-row tile, chunk kc (as in gemm_pp_kernel)
+  unsigned offs[HSLOTS];
+  if (wm == 1) {
+    const int kc = lane & 7;
+#pragma unroll
+    for (int s_ = 0; s_ < HSLOTS; ++s_) {
+      const int id = 4 * s_ + wq, hp = 8 * id + (lane >> 3);
+      const int hy = hp / HC, hx = hp - hy * HC;
+      const int y = y0 - 1 + hy, xx = x0 - 1 + hx;
+      const bool ok = id < HPIECES && hp < HPIX && (unsigned)y < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
+      const int sc = kc ^ ((hp >> 1) & 7);
+      const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)y * p.Win + xx) * p.a_pix_stride + sc * 8;
+      offs[s_] = ok ? (unsigned)(e * 2) : OOB;
+    }
+  } else {
+    const int t = tid & 255, kc = t & 7, r0 = t >> 3;
+    const int sc = kc ^ ((r0 >> 1) & 7);
+#pragma unroll
+    for (int j = 0; j < HSLOTS; ++j) offs[j] = j < 8 ? (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2) : 0u;
+  }
+  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
+
+  // halo pieces of slots S0, S0 + 1 (static) of the chunk at channel C0 into halo buffer DST
+#define DPTX_HALO_ISSUE_A(DST, S0, C0)                                                                             \
+  do {                                                                                                             \
+    _Pragma("unroll") for (int s_ = (S0); s_ < (S0) + 2; ++s_) {                                                   \
+      if (s_ < HSLOTS && 4 * s_ + wq < HPIECES)                                                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
+            rsrcA, (__attribute__((address_space(3))) void*)((DST) + (4 * s_ + wq) * 1024), 16,                    \
+            offs[s_ < HSLOTS ? s_ : 0] == OOB ? OOB : offs[s_ < HSLOTS ? s_ : 0] + (unsigned)((C0) * 2), 0, 0, 0); \
+    }                                                                                                              \
+  } while (0)
+  // the eight W pieces of (tap TAP, channel chunk C0) into W buffer DST
+#define DPTX_HALO_ISSUE_W(DST, TAP, C0)                                                                            \
+  do {                                                                                                             \
+    char* d_ = (DST) + wq * 1024;                                                                                  \
+    const unsigned wk_ = (unsigned)(((TAP) * p.Cin + (C0)) * 2);                                                   \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(d_ + 32 * j * 128), 16, \
+                                               offs[j] + wk_, 0, 0, 0);                                            \
+  } while (0)
+
+  // fragment reads: A block i = output row 4 wm + i, lane lr = pixel; tap (ky, kx) shifts the halo pixel by ky*34 + kx
+  // (the halo offsets of all nine unrolled taps are loop-invariant; left to itself hipcc hoists the 144 of them out of the
+  // chunk loop and spills -- hp0 is made opaque once per tap so that they are recomputed, ~60 VALU per 32 MFMAs)
+  int hp0 = wm * 4 * HC + lr;
+  auto read = [&](PpFrags& f, const char* hb, const char* sb, int delta, int ks) {
+    const int chunk = 2 * ks + lh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hp = hp0 + i * HC + delta;
+      f.a[i] = *(const u32x4_t*)(hb + hp * 128 + ((chunk ^ ((hp >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wn * 64 + j * 32 + lr;
+      f.b[j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    }
+  };
+  PpFrags f0, f1;
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto mma_tap = [&](const char* hb, const char* sb, int delta) {
+    asm volatile("" : "+v"(hp0));
+    read(f0, hb, sb, delta, 0);
+    read(f1, hb, sb, delta, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    pp_mma<DT, RELU_A>(f0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    read(f0, hb, sb, delta, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    pp_mma<DT, RELU_A>(f1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    read(f1, hb, sb, delta, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    pp_mma<DT, RELU_A>(f0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    pp_mma<DT, RELU_A>(f1, acc);
+  };
+
+  const int nch = p.Cin / BK;
+  // prologue: the whole halo of chunk 0 (group 1) and W of (tap 0, chunk 0) (group 0)
+  if (wm == 0) {
+    DPTX_HALO_ISSUE_W(w_ptr(0), 0, 0);
+  } else {
+#pragma unroll
+    for (int s0 = 0; s0 < HSLOTS + 1; s0 += 2) DPTX_HALO_ISSUE_A(h_ptr(0), s0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wm == 0) {
+    for (int cc = 0; cc < nch; ++cc) {
+      const char* hb = h_ptr(cc & 1);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int wb = (cc + tap) & 1;
+        // slot 1: W of the next (tap, chunk)
+        if (tap < 8) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), tap + 1, cc * BK);
+        else if (cc + 1 < nch) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), 0, (cc + 1) * BK);
+        asm volatile("s_barrier" ::: "memory");
+        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);        // slot 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+      }
+    }
+  } else {
+    for (int cc = 0; cc < nch; ++cc) {
+      const char* hb = h_ptr(cc & 1);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int wb = (cc + tap) & 1;
+        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);        // slot 1
+        if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's halo (issued in taps 0..5)
+        asm volatile("s_barrier" ::: "memory");
+        if (2 * tap < HSLOTS && cc + 1 < nch) DPTX_HALO_ISSUE_A(h_ptr((cc + 1) & 1), 2 * tap, (cc + 1) * BK);  // slot 2
+        asm volatile("s_barrier" ::: "memory");
+      }
+    }
+  }
+#undef DPTX_HALO_ISSUE_W
+#undef DPTX_HALO_ISSUE_A
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m_base, n0, wm, wn, lr, lh, tid, acc, p.Win);
+#endif
+}
+
 // ------------------------------------------------------------------- phased 256x256 kernel
 // Four phases per k-tile, two barriers per phase, the two wave groups (wm = 0 / 1) one barrier apart:
 //
@@ -1325,6 +1513,38 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// Shapes gemm_halo_kernel accepts: 3x3 / stride 1 / pad 1 on a dense NHWC map whose width is a multiple of 32 and height a
+// multiple of 8, Cin % 64 == 0, N % 256 == 0, 16-bit operands, no GroupNorm statistics.  launch_gemm forces k_tap_fast for
+// them whichever kernel ends up running, so that the k order -- and with it every bit of the result -- is the same.
+static bool halo_shape(const GemmParams& p) {
+  // Measured (profiles/r02_experiments.md): 917 vs 949 TF/s on rcu@96 -- the 1.7x fewer DMA bytes do not pay, the loop is
+  // bound by the ping-pong structure (one group's 32 MFMAs + first-read latency + barrier per slot), not by operand
+  // traffic.  Off unless DPTX_HALO=1.
+  static int on = -1;
+  if (on < 0) { const char* t = getenv("DPTX_HALO"); on = (t && t[0] == '1') ? 1 : 0; }
+  return on && p.ksz == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.Wout == p.Win && p.a_rpi == p.Hin * p.Win &&
+         p.Win % 32 == 0 && p.Hin % 8 == 0 && p.Cin % 64 == 0 && p.N % 256 == 0 && p.K == 9 * p.Cin && !p.a_fp32 &&
+         p.gn_part == nullptr && p.M % p.a_rpi == 0 && p.c_rpi == 0x7fffffff && p.a_bytes > 0 && p.a_bytes < (1ll << 31) &&
+         (long long)p.N * p.ldw * 2 < (1ll << 31);
+}
+
+template <int DT>
+static hipError_t launch_halo(const GemmParams& p, hipStream_t stream) {
+  const int tiles_m = (p.M / p.a_rpi) * (p.Win / 32) * (p.Hin / 8), tiles_n = p.N / 256;
+  GemmParams q = p;
+  choose_xcd_grid(p, tiles_m, tiles_n, q.xcd_m, q.xcd_n);
+  const int tiles = 8 * ((tiles_m + q.xcd_m - 1) / q.xcd_m) * (tiles_n / q.xcd_n);
+  constexpr size_t smem = 2 * 32 * 1024 + 2 * 44 * 1024;
+  auto go = [&](auto k) {
+    static bool done = false;
+    if (!done) { set_smem_attr(k, smem); done = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
+  };
+  if (p.a_relu) go(gemm_halo_kernel<DT, true>);
+  else go(gemm_halo_kernel<DT, false>);
+  return hipGetLastError();
+}
+
 template <int DT, int PL>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
@@ -1341,6 +1561,12 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // efficiency wins: fill of the last round of CUs (256 slots) x 1.25 (the measured per-tile advantage at K >= 512 with the
   // pipelined fragment reads, profiles/r02_experiments.md) against the fill of the 128x128 grid (512 slots).  That picks
   // it for the ViT GEMMs, patch-embed and the 3x3 convs at 1/4 resolution and keeps 128x128 for the small maps.
+  if constexpr (PL == 1 && DT != DT_FP8) {
+    // 3x3 convolutions on the large decoder maps: LDS-resident input halo (from 200 tiles up; below that the implicit
+    // GEMM's smaller tiles fill the chip better, and give the same bits)
+    if (halo_shape(p) && forced == 0 && (long long)(p.M / p.a_rpi) * (p.Win / 32) * (p.Hin / 8) * (p.N / 256) >= 200)
+      return launch_halo<DT>(p, stream);
+  }
   if constexpr (PL == 1) {
     const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
     static int min_k = -1;  // DPTX_T256_MINK: shortest K that takes the 256x256 tile (experiments)
@@ -1398,6 +1624,7 @@ hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
     return launch_dt<DT_FP8, 1>(p, stream);
   }
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 8 != 0) return hipErrorInvalidValue;
+  if (halo_shape(p)) p.k_tap_fast = 1;  // one k order for these shapes, whichever kernel runs them (all modes)
   if (mode == MODE_BF16) return launch_dt<DT_BF16, 1>(p, stream);
   if (mode == MODE_FP16) return launch_dt<DT_FP16, 1>(p, stream);
   if (mode == MODE_BF16X3) return launch_dt<DT_BF16, 2>(p, stream);
