@@ -637,9 +637,15 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 // issued TWO tiles ahead, after the W pieces of the next tile, and group 0's wait at the end of its MFMA slot is
 // vmcnt(4) -- the W pieces (L2-resident, quick) must have landed, the four A pieces (streamed from HBM / far L2, the ones
 // the convolutions were seen waiting for) get one more iteration.
-template <int DT, bool RELU_A, bool A3>
+//
+// VAR == 2 (G0ALL): group 0 issues ALL sixteen pieces of the next tile (group 1 none), so that a tile is complete when
+// group 0's vmcnt(0) and the barrier behind its MFMA slot have passed -- which lets group 0 fetch the first fragments of
+// its next MFMA slot BEFORE the barrier in front of that slot (the ~200 cycles of read latency the slot trace shows at
+// the head of every MFMA slot disappear from one of the two).
+template <int DT, bool RELU_A, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool A3 = VAR == 1, G0ALL = VAR == 2;
   constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
   constexpr int SLABS = TM;
   constexpr int HALF = 128 * 128;  // bytes of a 128-row operand tile
@@ -673,11 +679,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   const int kc = t & 7, r0 = t >> 3;
   const int sc = kc ^ ((r0 >> 1) & 7);
   const int a_row0 = wm == 0 ? 128 : 0;
-  int a_iy0[4], a_ix0[4];
-  unsigned a_off[4];
+  constexpr int NA = G0ALL ? 8 : 4;  // G0ALL: i = 4..7 are A rows 0..127, loaded by group 0 as well
+  int a_iy0[NA], a_ix0[NA];
+  unsigned a_off[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + a_row0 + r0 + 32 * i;
+  for (int i = 0; i < NA; ++i) {
+    const int m = m0 + (i < 4 ? a_row0 + r0 + 32 * i : r0 + 32 * (i - 4));
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
     int rem, ox;
@@ -708,16 +715,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     }                                                                                                              \
   } while (0)
   // this group's four A pieces of the tile at (ky, kx, c0) into the 128-row tile at DST; advances the tap
-#define DPTX_PP_ISSUE_A(DST)                                                                                       \
+#define DPTX_PP_ISSUE_A_ROWS(DST, I0)                                                                              \
   do {                                                                                                             \
     char* d_ = (DST) + wq * 1024;                                                                                  \
     const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
+      const int iy = a_iy0[(I0) + i] + ky, ix = a_ix0[(I0) + i] + kx;                                              \
       const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(d_ + 32 * i * 128), 16, \
-                                               valid ? a_off[i] + tap_ : OOB, 0, 0, 0);                            \
+                                               valid ? a_off[(I0) + i] + tap_ : OOB, 0, 0, 0);                     \
     }                                                                                                              \
+  } while (0)
+#define DPTX_PP_ISSUE_A(DST)                                                                                       \
+  do {                                                                                                             \
+    DPTX_PP_ISSUE_A_ROWS(DST, 0);                                                                                  \
     DPTX_PP_NEXT(ky, kx, c0);                                                                                      \
   } while (0)
   // the eight W pieces of the tile at (kyw, kxw, c0w) into the 256-row tile at DST; advances that tap
@@ -753,9 +764,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   // prologue: tile 0 (A3: also A rows 128..255 of tile 1)
   if (wm == 0) {
     DPTX_PP_ISSUE_W(w_ptr(0));
+    if (G0ALL) DPTX_PP_ISSUE_A_ROWS(alo_ptr(0), NA - 4);
     DPTX_PP_ISSUE_A(ahi_ptr(0));
     if (A3 && nk > 1) DPTX_PP_ISSUE_A(ahi_ptr(1));
-  } else {
+  } else if (!G0ALL) {
     DPTX_PP_ISSUE_A(alo_ptr(0));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -768,16 +780,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
       DPTX_STAMP(0);
       // slot 1: the DMA.  !A3: W and A rows 128..255 of tile kt+1.  A3: W of tile kt+1, then A rows 128..255 of tile kt+2.
+      const char* sa = alo_ptr(kt & 1);
+      const char* sb = w_ptr(kt & 1);
+      if (G0ALL) pp_read(f0, sa, sb, wn, lr, lh, 0);             // tile kt is complete: its first fragments now
       if (kt + 1 < nk) DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
       const bool more_a = A3 ? kt + 2 < nk : kt + 1 < nk;
+      if (G0ALL && more_a) DPTX_PP_ISSUE_A_ROWS(alo_ptr((kt + 1) & 1), NA - 4);
       if (more_a) DPTX_PP_ISSUE_A(ahi_ptr(A3 ? h_wr : (kt + 1) & 1));
       if (A3) h_wr = h_wr == 2 ? 0 : h_wr + 1;
       DPTX_STAMP(1);
       asm volatile("s_barrier" ::: "memory");
       DPTX_STAMP(2);
-      const char* sa = alo_ptr(kt & 1);                          // slot 2
-      const char* sb = w_ptr(kt & 1);
-      pp_read(f0, sa, sb, wn, lr, lh, 0);
+      if (!G0ALL) pp_read(f0, sa, sb, wn, lr, lh, 0);            // slot 2
       pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
       // what group 1 reads in its next slot has landed: everything (!A3), everything but the newest four pieces (A3)
       if (A3 && more_a) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -794,11 +808,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       if (A3) h_rd = h_rd == 2 ? 0 : h_rd + 1;
       pp_read(f0, sa, sb, wn, lr, lh, 0);
       pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // its DMA of the previous slot 2 (A rows 0..127 of THIS
+      if (!G0ALL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its DMA of the previous slot 2 (A rows 0..127 of THIS
       DPTX_STAMP(1);                                             // tile) has landed before group 0 reads it in slot 2
       asm volatile("s_barrier" ::: "memory");
       DPTX_STAMP(2);
-      if (kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
+      if (!G0ALL && kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
       DPTX_STAMP(3);
       asm volatile("s_barrier" ::: "memory");
     }
@@ -809,6 +823,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #undef DPTX_STAMP
 #undef DPTX_PP_ISSUE_W
 #undef DPTX_PP_ISSUE_A
+#undef DPTX_PP_ISSUE_A_ROWS
 #undef DPTX_PP_NEXT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1465,11 +1480,14 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       };
       constexpr size_t smem3 = 144 * 1024;
       if (pp == 3) {
-        if (p.a_relu) go(gemm_pp_kernel<DT, true, true>, smem3);
-        else go(gemm_pp_kernel<DT, false, true>, smem3);
+        if (p.a_relu) go(gemm_pp_kernel<DT, true, 1>, smem3);
+        else go(gemm_pp_kernel<DT, false, 1>, smem3);
+      } else if (pp == 4) {  // group 0 issues all sixteen pieces and pre-reads its first fragments
+        if (p.a_relu) go(gemm_pp_kernel<DT, true, 2>, smem);
+        else go(gemm_pp_kernel<DT, false, 2>, smem);
       } else {
-        if (p.a_relu) go(gemm_pp_kernel<DT, true, false>, smem);
-        else go(gemm_pp_kernel<DT, false, false>, smem);
+        if (p.a_relu) go(gemm_pp_kernel<DT, true, 0>, smem);
+        else go(gemm_pp_kernel<DT, false, 0>, smem);
       }
       return hipGetLastError();
     }
