@@ -127,40 +127,52 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
     }
     return;
   } else {
+    // hi/lo planes, 3 MFMAs per product.  The fragment reads run one k-step ahead of the MFMAs (two fragment sets): the
+    // 2 (TM + TN) ds_read_b128 of k-step ks+1 are in flight under the 3 TM TN MFMAs of k-step ks
+    // (DPTX_X3_NOPIPE: read, then multiply, per k-step -- the round-1 form, for A/B runs)
+    u32x4_t af[2][TM], bf[2][TN], al[2][TM], bl[2][TN];
+    auto read = [&](int s_, int ks) {
+      const int chunk = 2 * ks + lh;
 #pragma unroll
-  for (int ks = 0; ks < BK / 16; ++ks) {
-    const int chunk = 2 * ks + lh;
-    u32x4_t af[TM], bf[TN], al[TM], bl[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row = wm * (TM * 32) + i * 32 + lr;
-      const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-      af[i] = *(const u32x4_t*)(sa + off);
-      if (PL == 2) {
-        al[i] = *(const u32x4_t*)(sa + a_lo + off);
-        if (RELU_A) relu8_planes(af[i], al[i]);
-      } else if (RELU_A) {
-        af[i] = relu8(af[i]);
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + lr;
+        const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        af[s_][i] = *(const u32x4_t*)(sa + off);
+        al[s_][i] = *(const u32x4_t*)(sa + a_lo + off);
       }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = wn * (TN * 32) + j * 32 + lr;
-      const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-      bf[j] = *(const u32x4_t*)(sb + off);
-      if (PL == 2) bl[j] = *(const u32x4_t*)(sb + b_lo + off);
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (PL == 2) {  // small cross terms first, then the leading term
-          acc[i][j] = T16<DT>::mfma32(al[i], bf[j], acc[i][j]);
-          acc[i][j] = T16<DT>::mfma32(af[i], bl[j], acc[i][j]);
-        }
-        acc[i][j] = T16<DT>::mfma32(af[i], bf[j], acc[i][j]);
+        const int row = wn * (TN * 32) + j * 32 + lr;
+        const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        bf[s_][j] = *(const u32x4_t*)(sb + off);
+        bl[s_][j] = *(const u32x4_t*)(sb + b_lo + off);
       }
-  }
+    };
+    auto mma = [&](int s_) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (RELU_A) relu8_planes(af[s_][i], al[s_][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {  // small cross terms first, then the leading term
+          acc[i][j] = T16<DT>::mfma32(al[s_][i], bf[s_][j], acc[i][j]);
+          acc[i][j] = T16<DT>::mfma32(af[s_][i], bl[s_][j], acc[i][j]);
+          acc[i][j] = T16<DT>::mfma32(af[s_][i], bf[s_][j], acc[i][j]);
+        }
+      }
+    };
+#ifdef DPTX_X3_NOPIPE
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) { read(0, ks); mma(0); }
+#else
+    read(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      if (ks + 1 < BK / 16) read((ks + 1) & 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
   }
 }
 
