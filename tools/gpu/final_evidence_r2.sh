@@ -13,6 +13,9 @@ for cfg in "--dtype mixed" "--dtype fp16x3" "--dtype fp16" "--task depth" "--tas
   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $cfg > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$cfg', d['value'], d['ms_per_step'])"
 done
 DPTX_STREAMS=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_1stream.log 2>&1; tail -1 $O/bench_1stream.log | cut -c1-120
+# DPT-Large: bf16 line with the mixed parity mode timed and checked beside it
+timeout 400 python bench.py --backbone vitl16_384 --task depth --steps 8 --warmup 3 > $O/bench_vitl16.log 2>&1; tail -1 $O/bench_vitl16.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('vitl16', d['value'], d['roofline']['frac'], d['parity'])"
+timeout 300 python tools/gemm_bench.py --only cal.4096,cal.8192,vit.qkv,vit.proj,vit.fc1,vit.fc2,rcu@96,rcu@48,head.0,l2_rn,l3_rn,s2.c1,s2.c2,s2.c3 --iters 30 > $O/gemm_shapes.txt 2>&1; grep TF/s $O/gemm_shapes.txt | tail -16
 timeout 600 python tools/precision_frontier.py --steps 10 --out $O/frontier.md > $O/frontier.log 2>&1; tail -3 $O/frontier.log
 cd /tmp
 export DPTX_STREAMS=1   # kernel-level passes: one launch per layer over the whole batch (the bench's per-launch figures)
