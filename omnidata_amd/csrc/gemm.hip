@@ -1,1631 +1,10 @@
-// gemm.hip -- implicit-GEMM MFMA kernels for every linear / 1x1 / 3x3 / 7x7(im2col'd) layer of
-// DPT-Hybrid (SURVEY.md A.6 lists the 44 unique shapes).  gfx950 only.
-//
-//   C[M,N] = epilogue( gatherA[M,K] * W[N,K]^T )
-//
-// * v_mfma_f32_32x32x16_{bf16,f16}: a wave owns a (TM*32) x (TN*32) accumulator block.
-// * BK = 64: one k-tile of A / W is [rows][64] 16-bit = 128 B per row in LDS; the 16-B chunks of a
-//   row are XOR-swizzled with ((row>>1)&7), which makes the ds_read_b128 fragment reads (16
-//   distinct rows per lane group, same k chunk) bank-conflict free.
-// * gemm_glds_kernel (default): both operands stream HBM/L2 -> LDS with `buffer_load_dwordx4 ...
-//   lds` (no VGPR round trip, no ds_write).  The LDS image of a wave-instruction is lane-linear
-//   (8 rows x 128 B), so the swizzle is applied to the per-lane SOURCE chunk; out-of-image conv
-//   taps and rows >= M use an out-of-range buffer offset, which the hardware returns as zeros.
-//   Two LDS stages: the loads of tile t+1 are in flight while tile t is multiplied; one
-//   vmcnt(0)+barrier per k-tile.
-// * gemm_reg_kernel: register-staged variant of the same tiling, used when A is fp32 (the
-//   ProjectReadout GEMM reads the fp32 token stream and rounds while staging) or when the A
-//   buffer is too large for a 32-bit buffer offset.
-// * A is gathered as NHWC conv taps, so dense GEMM, strided 1x1 and kxk convolutions share the
-//   loader; optional ReLU on the A fragments (RCU pre-activation, one v_pk_max_i16 per dword).
-// * epilogue: accumulators -> LDS fp32 tile -> coalesced 16-B rows with fused bias, ReLU /
-//   erf-GELU, up to two residuals (16-bit or fp32, one may broadcast over images), 16-bit or
-//   fp32 output, optional row remap (token rows skip the cls slot).
-// * 1-D grid, XCD-aware bijective remap; n-tile fastest so the blocks of one XCD re-use the
-//   same A rows out of that XCD's L2.
-#include <cstdlib>
-#include <type_traits>
-
-#include "common.h"
-#include "kernels.h"
+// gemm.hip -- launch_gemm and the single-plane bf16 instantiations of the implicit-GEMM kernels (gemm_impl.h).
+#include "gemm_impl.h"
 
 namespace dptx {
 
-constexpr int BK = 64;
-
-// q = m / d, rem = m % d for 0 <= m < 2^23 without the ~35-instruction integer division: float(m) is exact, the product
-// with the rounded reciprocal is off by < 1, one correction step either way.  `big` (uniform): exact division.
-__device__ __forceinline__ int row_div(int m, int d, float rcp, bool big, int& rem) {
-  if (big) {
-    const int q = m / d;
-    rem = m - q * d;
-    return q;
-  }
-  int q = (int)((float)m * rcp);
-  int r = m - q * d;
-  if (r < 0) { --q; r += d; }
-  if (r >= d) { ++q; r -= d; }
-  rem = r;
-  return q;
-}
-
-// ----------------------------------------------------------------------------- shared pieces
-template <int DT, int TM, int TN, bool RELU_A, int PL = 1, int HK = BK / 16>
-__device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_lo, int b_lo, int wm, int wn, int lr, int lh,
-                                         f32x16_t (&acc)[TM][TN]) {
-  // a_lo / b_lo: byte distance of the lo-plane tiles inside the stage (PL == 2)
-  if constexpr (DT == DT_FP8) {
-    // a row of the k-tile is 128 e4m3 bytes.  v_mfma_scale_f32_32x32x64_f8f6f4 (format 0 = e4m3 for both operands, E8M0
-    // scale 127 = 1.0 in every byte of the scale registers: a plain fp8 MFMA at twice the bf16 rate) contracts 64 k per
-    // instruction; lane (lr, lh) supplies 32 consecutive bytes of its row -- the two 16-B chunks 4q + 2lh, 4q + 2lh + 1
-    // of MFMA q = 0, 1.  A and W use the same byte -> k assignment, so the contraction over the 128 bytes is complete
-    // whatever k order the instruction uses internally.
-    static_assert(PL == 1 && !RELU_A, "fp8: single plane; the producer writes the ReLU'd copy");
-    typedef int i32x8_t __attribute__((ext_vector_type(8)));
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      i32x8_t af[TM], bf[TN];
-      const int c0 = 4 * q + 2 * lh;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (TM * 32) + i * 32 + lr;
-        const int sw = (row >> 1) & 7;
-        const u32x4_t lo = *(const u32x4_t*)(sa + row * 128 + ((c0 ^ sw) << 4));
-        const u32x4_t hi = *(const u32x4_t*)(sa + row * 128 + (((c0 + 1) ^ sw) << 4));
-        af[i] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * (TN * 32) + j * 32 + lr;
-        const int sw = (row >> 1) & 7;
-        const u32x4_t lo = *(const u32x4_t*)(sb + row * 128 + ((c0 ^ sw) << 4));
-        const u32x4_t hi = *(const u32x4_t*)(sb + row * 128 + (((c0 + 1) ^ sw) << 4));
-        bf[j] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-    }
-    return;
-  } else if constexpr (PL == 1) {
-    // all fragment reads of the k-tile are issued up front (16 ds_read_b128 in flight for a 64x64 wave tile,
-    // 64 VGPRs) and the MFMAs consume them behind counted lgkmcnt waits: the LDS latency is paid once per
-    // k-tile instead of once per k-step
-    // (HK k-steps per group: 4 = the whole k-tile for 64x64 wave tiles; 2 for the 128x64 wave tile of the
-    // 256x256 block, whose 128 accumulator registers leave room for 48 fragment registers, not 96)
-#pragma unroll
-    for (int g = 0; g < BK / 16; g += HK) {
-      u32x4_t af[HK][TM], bf[HK][TN];
-#pragma unroll
-      for (int ks = 0; ks < HK; ++ks) {
-        const int chunk = 2 * (g + ks) + lh;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = wm * (TM * 32) + i * 32 + lr;
-          af[ks][i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = wn * (TN * 32) + j * 32 + lr;
-          bf[ks][j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler otherwise sinks them
-                                          // back to one k-step of look-ahead to save registers)
-#pragma unroll
-      for (int ks = 0; ks < HK; ++ks) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          if (RELU_A) af[ks][i] = relu8(af[ks][i]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = T16<DT>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
-        }
-      }
-      if (HK != BK / 16) __builtin_amdgcn_sched_barrier(0);
-    }
-    return;
-  } else {
-    // hi/lo planes, 3 MFMAs per product.  The fragment reads run one k-step ahead of the MFMAs (two fragment sets): the
-    // 2 (TM + TN) ds_read_b128 of k-step ks+1 are in flight under the 3 TM TN MFMAs of k-step ks
-    // (DPTX_X3_NOPIPE: read, then multiply, per k-step -- the round-1 form, for A/B runs)
-    u32x4_t af[2][TM], bf[2][TN], al[2][TM], bl[2][TN];
-    auto read = [&](int s_, int ks) {
-      const int chunk = 2 * ks + lh;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (TM * 32) + i * 32 + lr;
-        const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-        af[s_][i] = *(const u32x4_t*)(sa + off);
-        al[s_][i] = *(const u32x4_t*)(sa + a_lo + off);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * (TN * 32) + j * 32 + lr;
-        const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-        bf[s_][j] = *(const u32x4_t*)(sb + off);
-        bl[s_][j] = *(const u32x4_t*)(sb + b_lo + off);
-      }
-    };
-    auto mma = [&](int s_) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (RELU_A) relu8_planes(af[s_][i], al[s_][i]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {  // small cross terms first, then the leading term
-          acc[i][j] = T16<DT>::mfma32(al[s_][i], bf[s_][j], acc[i][j]);
-          acc[i][j] = T16<DT>::mfma32(af[s_][i], bl[s_][j], acc[i][j]);
-          acc[i][j] = T16<DT>::mfma32(af[s_][i], bf[s_][j], acc[i][j]);
-        }
-      }
-    };
-#ifdef DPTX_X3_NOPIPE
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) { read(0, ks); mma(0); }
-#else
-    read(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      if (ks + 1 < BK / 16) read((ks + 1) & 1, ks + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(ks & 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
-  }
-}
-
-// SLABS == 1: the whole BM x BN tile goes through LDS at once.  SLABS == TM (256x256 block: the fp32 tile would be
-// 266 KB): TM passes, pass s carries the s-th 32-row MFMA tile of every wave -- LDS row q = (wave row)*32 + r is tile
-// row (q/32)*(TM*32) + s*32 + q%32.
-//
-// Memory-level parallelism: a thread owns ITER rows x 8 columns of a slab.  All of its residual / per-image-bias loads
-// are issued BEFORE the accumulators are staged through LDS, so their latency (1-2 us next to a second busy block) is
-// paid once per slab under the staging, not once per row; with C == R1 (the in-place residual stream) every thread
-// reads exactly the elements it later writes, so the order loads -> stores is also what makes that legal.
-//
-// GroupNorm statistics (p.gn_part): per 32-row MFMA block and group, (sum, sum of squares) of the fp32 accumulators,
-// reduced in a fixed order (16 registers, lane^32, then lane^1..cpg/2) and written -- not accumulated -- to
-// partial[img][block][group]: no atomics, and the value of a record depends on the image's own rows only, so the
-// statistics are bit-identical run to run and at every batch size (needs rows-per-image % 32 == 0; the engine falls
-// back to the gn_stats kernel otherwise).
-//
-// ILV (gemm_ph_kernel, 256x256, 2 x 4 waves): a wave's 4 x 2 MFMA blocks are interleaved over the tile -- row block i of
-// wave row wm sits at tile row (i>>1)*128 + wm*64 + (i&1)*32, column block j of wave column wn at j*128 + wn*32 -- so that
-// the four 128-row half-tiles of a k-tile are needed one phase after the other.
-template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false>
-__device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
-                                         int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0) {
-  // row_pitch != 0 (gemm_halo_kernel): the tile is 8 image rows x 32 pixels -- tile row R is GEMM row
-  // m0 + (R >> 5) * row_pitch + (R & 31)
-  static_assert(SLABS == 1 || SLABS == TM, "one slab, or one per MFMA row tile");
-  static_assert(!ILV || (SLABS == TM && TM == 4 && TN == 2 && BM == 256 && BN == 256), "interleaved mapping: the phased kernel");
-  constexpr int CT_PITCH = BN + 4;  // floats
-  constexpr int CT_ROWS = BM / SLABS;
-  constexpr int NCH = BN / 8;     // 8-column chunks per tile row
-  constexpr int RPP = NT / NCH;   // tile rows per pass
-  constexpr int ITER = CT_ROWS / RPP;
-  static_assert(CT_ROWS % RPP == 0, "rows per pass must divide the slab");
-  float* ct = (float*)smem;
-  const int cn = tid % NCH;
-  const int rr = tid / NCH;
-  const int n = n0 + cn * 8;
-
-  if (p.gn_part != nullptr) {
-    const int cpg = p.gn_cpg;  // channels per group: 2..32, a power of two
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      // first GEMM row of this wave's i-th 32-row block
-      const int mb = m0 + (ILV ? (i >> 1) * 128 + wm * 64 + (i & 1) * 32 : (wm * TM + i) * 32);
-      const int img = mb / p.gn_hw;
-      const int blk = (mb - img * p.gn_hw) >> 5;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float sm = 0.f, sq = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sm += v; sq = fmaf(v, v, sq); }
-        sm += __shfl_xor(sm, 32, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        for (int o = 1; o < cpg; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
-        if (lh == 0 && (lr & (cpg - 1)) == 0 && mb < p.M) {
-          const int g = (n0 + (ILV ? j * 128 + wn * 32 : (wn * TN + j) * 32) + lr) / cpg;
-          float2* dst = (float2*)p.gn_part + ((long long)img * p.gn_blocks + blk) * 32 + g;
-          *dst = make_float2(sm, sq);
-        }
-      }
-    }
-  }
-
-  float bias_c[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias_c[e] = 0.f;
-  if (p.bias != nullptr && !p.bias_per_img) {
-    const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
-    bias_c[0] = b0.x; bias_c[1] = b0.y; bias_c[2] = b0.z; bias_c[3] = b0.w;
-    bias_c[4] = b1.x; bias_c[5] = b1.y; bias_c[6] = b1.z; bias_c[7] = b1.w;
-  }
-  const bool remap = p.c_rpi != 0x7fffffff;  // token-row remap (patch-embed, readout); everything else skips the division
-  // rows per load group: 4 (96 registers of loads in flight at most); 2 for the slab epilogue, whose 128 accumulator
-  // registers stay live across the slabs
-  constexpr int GR = SLABS > 1 ? 2 : (ITER < 4 ? ITER : 4);
-  constexpr int NGR = ITER / GR;
-  static_assert(ITER % GR == 0, "row groups");
-
-  // The body is instantiated per residual configuration (R1M / R2M: 0 none, 1 16-bit, 2 fp32, -1 decided at run time;
-  // BPI: per-image bias 0 / 1 / -1) and selected by ONE uniform branch below: inside an instance the loads are
-  // unconditional, so the compiler keeps them where they are written -- all up front -- instead of sinking each one
-  // into the conditional block that consumes it (which serialises a memory latency per row).
-  auto body = [&](auto r1m_, auto r2m_, auto bpi_) {
-    constexpr int R1M = decltype(r1m_)::value, R2M = decltype(r2m_)::value, BPI = decltype(bpi_)::value;
-    const bool r1 = R1M < 0 ? p.R1 != nullptr : R1M > 0, r2 = R2M < 0 ? p.R2 != nullptr : R2M > 0;
-    const bool r1f = R1M < 0 ? p.r1_fp32 != 0 : R1M == 2, r2f = R2M < 0 ? p.r2_fp32 != 0 : R2M == 2;
-    const bool bpi = BPI < 0 ? p.bias_per_img != 0 : BPI > 0;
-    long long coff[GR];
-    bool ok[GR];
-    u32x4_t ra[GR][2], rb[GR][2], bb[GR][2];
-    // addresses and every global load of row group `gi` of slab `s`
-    auto issue_loads = [&](int s, int gi) {
-#pragma unroll
-      for (int it = 0; it < GR; ++it) {
-        const int row = rr + (gi * GR + it) * RPP;
-        int R = SLABS == 1 ? row
-                : ILV      ? (s >> 1) * 128 + (row >> 5) * 64 + (s & 1) * 32 + (row & 31)
-                           : (row >> 5) * (TM * 32) + s * 32 + (row & 31);
-        if (row_pitch) R = (R >> 5) * row_pitch + (R & 31);
-        int m = m0 + R;
-        ok[it] = m < p.M;
-        m = ok[it] ? m : m0;  // any valid row: the loads stay in bounds, the store is masked
-        int img = 0, pp = m;
-        if (remap) {
-          img = m / p.c_rpi;
-          pp = m - img * p.c_rpi;
-        }
-        const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
-        coff[it] = crow * p.ldc + n;
-        if (r1) {
-          if (r1f) {
-            const u32x4_t* src = (const u32x4_t*)((const float*)p.R1 + coff[it]);
-            ra[it][0] = src[0];
-            ra[it][1] = src[1];
-          } else {
-            ra[it][0] = *(const u32x4_t*)((const uint16_t*)p.R1 + coff[it]);
-            if (PL == 2) ra[it][1] = *(const u32x4_t*)((const uint16_t*)p.R1 + p.planes.act + coff[it]);
-          }
-        }
-        if (r2) {
-          const long long off = p.r2_bcast ? (long long)(p.c_row_off + pp) * p.ldc + n : coff[it];
-          if (r2f) {
-            const u32x4_t* src = (const u32x4_t*)((const float*)p.R2 + off);
-            rb[it][0] = src[0];
-            rb[it][1] = src[1];
-          } else {
-            rb[it][0] = *(const u32x4_t*)((const uint16_t*)p.R2 + off);
-            if (PL == 2) rb[it][1] = *(const u32x4_t*)((const uint16_t*)p.R2 + p.planes.act + off);
-          }
-        }
-        if (bpi) {
-          const u32x4_t* src = (const u32x4_t*)(p.bias + (long long)img * p.N + n);
-          bb[it][0] = src[0];
-          bb[it][1] = src[1];
-        }
-      }
-    };
-#pragma unroll
-    for (int s = 0; s < SLABS; ++s) {
-      // ---- (a) the first row group's loads fly while the accumulators are staged
-      issue_loads(s, 0);
-      // ---- (b) accumulators -> LDS
-      if (s > 0) __syncthreads();  // the previous slab has been read out
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (SLABS != 1 && i != s) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ml = (SLABS == 1 ? wm * (TM * 32) + i * 32 : wm * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int nl = (ILV ? j * 128 + wn * 32 : wn * (TN * 32) + j * 32) + lr;
-            ct[ml * CT_PITCH + nl] = acc[i][j][r];
-          }
-      }
-      __syncthreads();
-      // ---- (c) rows out
-#pragma unroll
-      for (int gi = 0; gi < NGR; ++gi) {
-        if (gi > 0) issue_loads(s, gi);
-#pragma unroll
-        for (int it = 0; it < GR; ++it) {
-          const int row = rr + (gi * GR + it) * RPP;
-          float v[8];
-          {
-            const float4 x0 = *(const float4*)(ct + row * CT_PITCH + cn * 8);
-            const float4 x1 = *(const float4*)(ct + row * CT_PITCH + cn * 8 + 4);
-            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
-            v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          }
-#ifndef DPTX_NO_F8EPI   // A/B builds: what do the fp8 hooks cost the 16-bit kernels?
-          if (p.out_scale != 0.f) {  // fp8 GEMMs: the weights were scaled by a power of two before quantisation
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-          }
-#endif
-          if (bpi) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(bb[it][0][e]); v[4 + e] += __uint_as_float(bb[it][1][e]); }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bias_c[e];
-          }
-          if (p.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-          } else if (p.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-          }
-          if (r1) {
-            if (r1f) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(ra[it][0][e]); v[4 + e] += __uint_as_float(ra[it][1][e]); }
-            } else {
-              float f[8];
-              unpack8x<DT, PL>(ra[it][0], ra[it][1], f);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += f[e];
-            }
-          }
-          if (r2) {
-            if (r2f) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(rb[it][0][e]); v[4 + e] += __uint_as_float(rb[it][1][e]); }
-            } else {
-              float f[8];
-              unpack8x<DT, PL>(rb[it][0], rb[it][1], f);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += f[e];
-            }
-          }
-          if (ok[it]) {
-            if (p.c_fp32) {
-              float* cp = (float*)p.C + coff[it];
-              *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
-              *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-              store8f<DT, PL>((uint16_t*)p.C + coff[it], p.planes.act, v);
-            }
-#ifndef DPTX_NO_F8EPI
-            if (p.C8 != nullptr) {  // e4m3 copy for an fp8 consumer (ReLU'd first when every consumer pre-activates)
-              if (p.q_relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-              }
-              *(uint2*)((uint8_t*)p.C8 + coff[it]) = pack_fp8x8(v);
-            }
-#endif
-          }
-        }
-      }
-    }
-  };
-  using std::integral_constant;
-  const bool has1 = p.R1 != nullptr, has2 = p.R2 != nullptr;
-  if (!has1 && !has2 && !p.bias_per_img)
-    body(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // qkv, fc1, most convs
-  else if (has1 && p.r1_fp32 && !has2 && !p.bias_per_img)
-    body(integral_constant<int, 2>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // proj, fc2: fp32 stream
-  else if (has1 && !p.r1_fp32 && !has2 && !p.bias_per_img)
-    body(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // RCU conv2
-  else if (has1 && !p.r1_fp32 && has2 && !p.r2_fp32 && !p.bias_per_img)
-    body(integral_constant<int, 1>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{});  // RCU conv2 + path
-  else
-    body(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});  // patch-embed, readout
-}
-
-// ------------------------------------------------------------------- direct-to-LDS kernel
-constexpr unsigned OOB = 0x80000000u;  // >= any buffer size we bind (a_bytes < 2^31): reads as zero
-
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A, int PL>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_glds_kernel(const GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the buffer/LDS-DMA builtins exist only in the device pass
-  constexpr int NT = 64 * WAVES_M * WAVES_N;  // 256 threads (2 blocks/CU), or 512 for the 256x256 tile (1 block/CU)
-  static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
-  constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-  constexpr int ROWS_PP = NT / 8;                // tile rows one loader pass covers (8 threads x 16 B per 128-B row)
-  constexpr int PASS_BYTES = ROWS_PP * 128;
-  constexpr int A_PASSES = BM / ROWS_PP, B_PASSES = BN / ROWS_PP;
-  constexpr int HK = (TM * TN > 4) ? 2 : BK / 16;
-  constexpr int ES = DT == DT_FP8 ? 1 : 2;   // bytes per A / W element
-  constexpr int KE = 128 / ES;               // elements of K per k-tile (a tile row is 128 bytes)
-  constexpr int DTS = DT == DT_FP8 ? DT_BF16 : DT;  // type of C / residuals
-  constexpr int SLABS = (BM * (BN + 4) * 4 > 160 * 1024) ? TM : 1;
-  // stage image: [A hi][A lo (PL==2)][W hi][W lo (PL==2)]
-  constexpr int A_LO = BM * 128, B_BASE = PL * BM * 128, B_LO = BN * 128;
-  constexpr int STAGE_BYTES = PL * (BM + BN) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  // block -> tile: XCD x = blockIdx % 8 (observed dispatch placement; only speed depends on it) owns the
-  // (x / xcd_n)-th m-slice and (x % xcd_n)-th n-slice of the tile grid; inside a slice n runs fastest so
-  // consecutive blocks of one XCD share their A rows.
-  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
-  int m0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    m0 = mt * BM;
-    n0 = nt * BN;
-  }
-
-  // loader: thread (r0 = tid>>3, kc = tid&7) owns LDS chunk kc of rows r0 + 32*i and fetches the
-  // SOURCE chunk kc ^ ((r0>>1)&7)   ((row>>1)&7 is the same for every pass: 32*i leaves bits 1..3)
-  const int kc = tid & 7, r0 = tid >> 3;
-  const int sc = kc ^ ((r0 >> 1) & 7);
-  int a_iy0[A_PASSES], a_ix0[A_PASSES];
-  unsigned a_off[A_PASSES];  // byte offset of (img, iy0, ix0, source chunk), mod 2^32
-#pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + r0 + ROWS_PP * i;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    int rem, ox;  // M < 2^23 on this path (launch_cfg): reciprocal division
-    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
-    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
-    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;  // rows >= M never pass the bounds test
-    a_ix0[i] = ox * p.stride - p.pad_l;
-    const long long e = (long long)img * p.a_img_stride + p.a_off +
-                        ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * (16 / ES);
-    a_off[i] = (unsigned)(ok ? e * ES : 0);
-  }
-  unsigned w_off[B_PASSES];
-#pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + ROWS_PP * j) * p.ldw + sc * (16 / ES)) * ES);
-
-  const int w_bytes = (int)((long long)p.N * p.ldw * ES);
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
-  // lo planes (bf16x3 mode): same offsets, bases shifted by the plane distance
-  const __amdgpu_buffer_rsrc_t rsrcAl = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((uint16_t*)const_cast<void*>(p.A) + (PL == 2 ? p.planes.act : 0)), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcWl = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((uint16_t*)const_cast<void*>(p.W) + (PL == 2 ? p.planes.w : 0)), 0, w_bytes, 0x00020000);
-
-  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k tile being LOADED (wave-uniform)
-
-#define DPTX_ISSUE_TILE(BUF, K0)                                                                                   \
-  do {                                                                                                             \
-    char* sa_ = smem + (BUF) * STAGE_BYTES + wave * 1024;                                                          \
-    char* sb_ = sa_ + B_BASE;                                                                                      \
-    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * ES);                              \
-    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * ES);  /* k = (tap, channel) in W */          \
-    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                         \
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
-      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
-      const unsigned vo = valid ? a_off[i] + tap_ : OOB;                                                           \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(sa_ + i * PASS_BYTES), 16, vo, 0, \
-                                               0, 0);                                                              \
-      if (PL == 2)                                                                                                 \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcAl, (__attribute__((address_space(3))) void*)(sa_ + A_LO + i * PASS_BYTES), \
-                                                 16, vo, 0, 0, 0);                                                 \
-    }                                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) {                                                         \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(sb_ + j * PASS_BYTES), 16,   \
-                                               w_off[j] + wk_, 0, 0, 0);                                           \
-      if (PL == 2)                                                                                                 \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcWl, (__attribute__((address_space(3))) void*)(sb_ + B_LO + j * PASS_BYTES), \
-                                                 16, w_off[j] + wk_, 0, 0, 0);                                     \
-    }                                                                                                              \
-    if (p.k_tap_fast) { /* the nine taps re-read the same input lines in nine consecutive k-tiles (L2-resident) */ \
-      if (++kx == p.ksz) {                                                                                         \
-        kx = 0;                                                                                                    \
-        if (++ky == p.ksz) { ky = 0; c0 += KE; }                                                                   \
-      }                                                                                                            \
-    } else { /* channels-fastest inside a tap */                                                                   \
-      c0 += KE;                                                                                                    \
-      if (c0 >= p.Cin) {                                                                                           \
-        c0 = 0;                                                                                                    \
-        if (++kx == p.ksz) { kx = 0; ++ky; }                                                                       \
-      }                                                                                                            \
-    }                                                                                                              \
-  } while (0)
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / KE;
-  // debug trace (p.trace): per k-tile, lane 0 of every wave of block 0 stamps s_memtime after the barrier, after the DMA
-  // issue, after the MFMAs and after the wait for the next tile: where does an iteration's time go?
-  const bool tr = p.trace != nullptr && blockIdx.x == 0 && lane == 0;
-  long long* trp = p.trace + wave * 4 * 64;
-#ifdef DPTX_TRACE   // experiment builds only (build.py DPTX_CXXFLAGS=-DDPTX_TRACE): the stamps cost registers and issue slots
-#define DPTX_STAMP(SLOT) do { if (tr && kt < 64) trp[kt * 4 + (SLOT)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define DPTX_STAMP(SLOT) do { } while (0)
-#endif
-#ifdef DPTX_TRACE
-  if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
-#endif
-  DPTX_ISSUE_TILE(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed (every wave waits for its own DMA, then the barrier publishes all of
-    // them) and every wave is done reading the other stage, which the next DMA overwrites
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    DPTX_STAMP(3);
-    __syncthreads();
-    DPTX_STAMP(0);
-    const char* sa = smem + (kt & 1) * STAGE_BYTES;
-    if (kt + 1 < nk) DPTX_ISSUE_TILE((kt + 1) & 1, (kt + 1) * BK);
-    DPTX_STAMP(1);
-    mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, A_LO, B_LO, wm, wn, lr, lh, acc);
-    DPTX_STAMP(2);
-  }
-#ifdef DPTX_TRACE
-  if (tr && wave == 0) { trp[62 * 4 + 2] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 3] = (long long)wall_clock64(); }
-#endif
-#undef DPTX_STAMP
-#undef DPTX_ISSUE_TILE
-  __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
-  epilogue<DTS, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
-#endif
-}
-
-// Quarter-step software pipeline of the fragment reads for the 128x64 wave tile (TM = 4, TN = 2) of the 256x256 kernels:
-// the six ds_read_b128 of k-step q+1 are in flight under the eight MFMAs of k-step q (two fragment sets = 48 registers,
-// what mma_tile's HK = 2 grouping holds as well), so only the first read of a k-tile is exposed -- and pp_read can issue
-// that one before the barrier in front of the MFMA slot.
-struct PpFrags { u32x4_t a[4], b[2]; };
-// sa: the wave group's 128-row A tile, sb: the 256-row W tile
-__device__ __forceinline__ void pp_read(PpFrags& f, const char* sa, const char* sb, int wn, int lr, int lh, int ks) {
-  const int chunk = 2 * ks + lh;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 32 + lr;
-    f.a[i] = *(const u32x4_t*)(sa + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = wn * 64 + j * 32 + lr;
-    f.b[j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-  }
-}
-template <int DT, bool RELU_A>
-__device__ __forceinline__ void pp_mma(PpFrags& f, f32x16_t (&acc)[4][2]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (RELU_A) f.a[i] = relu8(f.a[i]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], acc[i][j]);
-  }
-}
-// k-steps 0..3 of one k-tile; f0 already holds (or has in flight) k-step 0
-template <int DT, bool RELU_A>
-__device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char* sa, const char* sb, int wn, int lr, int lh,
-                                            f32x16_t (&acc)[4][2]) {
-  pp_read(f1, sa, sb, wn, lr, lh, 1);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A>(f0, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_read(f0, sa, sb, wn, lr, lh, 2);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A>(f1, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_read(f1, sa, sb, wn, lr, lh, 3);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A>(f0, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A>(f1, acc);
-}
-
-// ------------------------------------------------------------------- ping-pong 256x256 kernel
-// The k-loop trace of gemm_glds_kernel (tools/gpu/gemm_trace.py, profiles/r02_gemm_trace.txt) shows what bounds the
-// 256x256 tile: an iteration is 4100 cycles for 2048 cycles of MFMA work per SIMD, because the eight waves run in
-// lockstep -- they all issue their 8 LDS-DMA instructions first (~100-170 cycles EACH, during which a wave issues nothing
-// else: 850-1400 cycles with the matrix pipe idle), then all read fragments, then the two waves of every SIMD queue their
-// MFMAs behind each other.  The DMA latency itself is hidden (the wait for the next tile is ~300 cycles).
-//
-// Here the two wave groups (wm = 0 / 1: the upper / lower 128 rows of the tile, one wave of each on every SIMD) run the
-// SAME work half an iteration apart, two barriers per k-tile:
-//     slot 1:  group 0 issues DMA for tile t+1          |  group 1 multiplies tile t
-//     slot 2:  group 0 multiplies tile t                |  group 1 issues DMA for tile t+1
-// so a SIMD always has one wave feeding the matrix pipe while the other is stuck in the DMA issue.  Who loads what follows
-// from who needs it first: group 1 multiplies tile t+1 in the very next slot after group 1's own issue slot, so everything
-// group 1 reads -- A rows 128..255 and all of W -- is issued by GROUP 0 one full slot earlier (12 instructions per wave),
-// and group 1 issues only A rows 0..127 (4 instructions), which group 0 reads a full iteration later.  Every wave drains
-// its own DMA (vmcnt(0)) at the end of its MFMA slot, i.e. before the barrier in front of the first reader.
-// A3: three LDS buffers for A rows 128..255 (the pieces group 0 issues and group 1 reads first), 144 KB in all: they are
-// issued TWO tiles ahead, after the W pieces of the next tile, and group 0's wait at the end of its MFMA slot is
-// vmcnt(4) -- the W pieces (L2-resident, quick) must have landed, the four A pieces (streamed from HBM / far L2, the ones
-// the convolutions were seen waiting for) get one more iteration.
-//
-// VAR == 2 (G0ALL): group 0 issues ALL sixteen pieces of the next tile (group 1 none), so that a tile is complete when
-// group 0's vmcnt(0) and the barrier behind its MFMA slot have passed -- which lets group 0 fetch the first fragments of
-// its next MFMA slot BEFORE the barrier in front of that slot (the ~200 cycles of read latency the slot trace shows at
-// the head of every MFMA slot disappear from one of the two).
-template <int DT, bool RELU_A, int VAR>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr bool A3 = VAR == 1, G0ALL = VAR == 2;
-  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
-  constexpr int SLABS = TM;
-  constexpr int HALF = 128 * 128;  // bytes of a 128-row operand tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // group = wm
-  const int lr = lane & 31, lh = lane >> 5;
-  // LDS map.  !A3: stage b = [A rows 0..127 | A rows 128..255 | W rows 0..255] at b * 64 KB.
-  //            A3: W x 2 at 0, A rows 0..127 x 2 at 64 KB, A rows 128..255 x 3 at 96 KB.
-  auto w_ptr = [&](int b) -> char* { return smem + (A3 ? b * 2 * HALF : b * 4 * HALF + 2 * HALF); };
-  auto alo_ptr = [&](int b) -> char* { return smem + (A3 ? 4 * HALF + b * HALF : b * 4 * HALF); };
-  auto ahi_ptr = [&](int h) -> char* { return smem + (A3 ? 6 * HALF + h * HALF : h * 4 * HALF + HALF); };
-
-  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
-  int m0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    m0 = mt * BM;
-    n0 = nt * BN;
-  }
-
-  // loader of a group: thread (r0 = t>>3, kc = t&7), t = tid % 256, owns LDS chunk kc of rows base + r0 + 32*i.
-  // Group 0 loads A rows 128..255 (4 passes) and W rows 0..255 (8 passes); group 1 loads A rows 0..127 (4 passes).
-  const int t = tid & 255;
-  const int kc = t & 7, r0 = t >> 3;
-  const int sc = kc ^ ((r0 >> 1) & 7);
-  const int a_row0 = wm == 0 ? 128 : 0;
-  constexpr int NA = G0ALL ? 8 : 4;  // G0ALL: i = 4..7 are A rows 0..127, loaded by group 0 as well
-  int a_iy0[NA], a_ix0[NA];
-  unsigned a_off[NA];
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int m = m0 + (i < 4 ? a_row0 + r0 + 32 * i : r0 + 32 * (i - 4));
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    int rem, ox;
-    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
-    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
-    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
-    a_ix0[i] = ox * p.stride - p.pad_l;
-    const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * 8;
-    a_off[i] = (unsigned)(ok ? e * 2 : 0);
-  }
-  unsigned w_off[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2);
-  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
-
-  // tap / channel offset (wave-uniform) of the k-tile whose A rows this group loads next, and (group 0) whose W rows
-  int ky = 0, kx = 0, c0 = 0, kyw = 0, kxw = 0, c0w = 0;
-  const int wq = wave & 3;     // wave inside its group: rows 8*wq .. 8*wq+7 of every 32-row pass
-#define DPTX_PP_NEXT(KY, KX, C0)                                                                                   \
-  do {                                                                                                             \
-    if (p.k_tap_fast) {                                                                                            \
-      if (++KX == p.ksz) { KX = 0; if (++KY == p.ksz) { KY = 0; C0 += BK; } }                                      \
-    } else {                                                                                                       \
-      C0 += BK;                                                                                                    \
-      if (C0 >= p.Cin) { C0 = 0; if (++KX == p.ksz) { KX = 0; ++KY; } }                                            \
-    }                                                                                                              \
-  } while (0)
-  // this group's four A pieces of the tile at (ky, kx, c0) into the 128-row tile at DST; advances the tap
-#define DPTX_PP_ISSUE_A_ROWS(DST, I0)                                                                              \
-  do {                                                                                                             \
-    char* d_ = (DST) + wq * 1024;                                                                                  \
-    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
-      const int iy = a_iy0[(I0) + i] + ky, ix = a_ix0[(I0) + i] + kx;                                              \
-      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(d_ + 32 * i * 128), 16, \
-                                               valid ? a_off[(I0) + i] + tap_ : OOB, 0, 0, 0);                     \
-    }                                                                                                              \
-  } while (0)
-#define DPTX_PP_ISSUE_A(DST)                                                                                       \
-  do {                                                                                                             \
-    DPTX_PP_ISSUE_A_ROWS(DST, 0);                                                                                  \
-    DPTX_PP_NEXT(ky, kx, c0);                                                                                      \
-  } while (0)
-  // the eight W pieces of the tile at (kyw, kxw, c0w) into the 256-row tile at DST; advances that tap
-#define DPTX_PP_ISSUE_W(DST)                                                                                       \
-  do {                                                                                                             \
-    char* d_ = (DST) + wq * 1024;                                                                                  \
-    const unsigned wk_ = (unsigned)((((kyw * p.ksz + kxw) * p.Cin) + c0w) * 2);                                    \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(d_ + 32 * j * 128), 16, \
-                                               w_off[j] + wk_, 0, 0, 0);                                           \
-    DPTX_PP_NEXT(kyw, kxw, c0w);                                                                                   \
-  } while (0)
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / BK;
-  const bool tr = p.trace != nullptr && blockIdx.x == 0 && lane == 0;
-  long long* trp = p.trace + wave * 4 * 64;
-#ifdef DPTX_TRACE   // experiment builds only (build.py DPTX_CXXFLAGS=-DDPTX_TRACE): the stamps cost registers and issue slots
-#define DPTX_STAMP(SLOT) do { if (tr && kt < 64) trp[kt * 4 + (SLOT)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define DPTX_STAMP(SLOT) do { } while (0)
-#endif
-#ifdef DPTX_TRACE
-  if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
-#endif
-  // prologue: tile 0 (A3: also A rows 128..255 of tile 1)
-  if (wm == 0) {
-    DPTX_PP_ISSUE_W(w_ptr(0));
-    if (G0ALL) DPTX_PP_ISSUE_A_ROWS(alo_ptr(0), NA - 4);
-    DPTX_PP_ISSUE_A(ahi_ptr(0));
-    if (A3 && nk > 1) DPTX_PP_ISSUE_A(ahi_ptr(1));
-  } else if (!G0ALL) {
-    DPTX_PP_ISSUE_A(alo_ptr(0));
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
-  // that hipcc resolves with copies: 500 spilled registers)
-  PpFrags f0, f1;
-  if (wm == 0) {
-    int h_wr = 2;  // A3: buffer of A rows 128..255 of tile kt + 2
-    for (int kt = 0; kt < nk; ++kt) {
-      DPTX_STAMP(0);
-      // slot 1: the DMA.  !A3: W and A rows 128..255 of tile kt+1.  A3: W of tile kt+1, then A rows 128..255 of tile kt+2.
-      const char* sa = alo_ptr(kt & 1);
-      const char* sb = w_ptr(kt & 1);
-      if (G0ALL) pp_read(f0, sa, sb, wn, lr, lh, 0);             // tile kt is complete: its first fragments now
-      if (kt + 1 < nk) DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
-      const bool more_a = A3 ? kt + 2 < nk : kt + 1 < nk;
-      if (G0ALL && more_a) DPTX_PP_ISSUE_A_ROWS(alo_ptr((kt + 1) & 1), NA - 4);
-      if (more_a) DPTX_PP_ISSUE_A(ahi_ptr(A3 ? h_wr : (kt + 1) & 1));
-      if (A3) h_wr = h_wr == 2 ? 0 : h_wr + 1;
-      DPTX_STAMP(1);
-      asm volatile("s_barrier" ::: "memory");
-      DPTX_STAMP(2);
-      if (!G0ALL) pp_read(f0, sa, sb, wn, lr, lh, 0);            // slot 2
-      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-      // what group 1 reads in its next slot has landed: everything (!A3), everything but the newest four pieces (A3)
-      if (A3 && more_a) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      DPTX_STAMP(3);
-      asm volatile("s_barrier" ::: "memory");
-    }
-  } else {
-    int h_rd = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      DPTX_STAMP(0);
-      const char* sa = ahi_ptr(A3 ? h_rd : kt & 1);              // slot 1
-      const char* sb = w_ptr(kt & 1);
-      if (A3) h_rd = h_rd == 2 ? 0 : h_rd + 1;
-      pp_read(f0, sa, sb, wn, lr, lh, 0);
-      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-      if (!G0ALL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its DMA of the previous slot 2 (A rows 0..127 of THIS
-      DPTX_STAMP(1);                                             // tile) has landed before group 0 reads it in slot 2
-      asm volatile("s_barrier" ::: "memory");
-      DPTX_STAMP(2);
-      if (!G0ALL && kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
-      DPTX_STAMP(3);
-      asm volatile("s_barrier" ::: "memory");
-    }
-  }
-#ifdef DPTX_TRACE
-  if (tr && wave == 0) { trp[62 * 4 + 2] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 3] = (long long)wall_clock64(); }
-#endif
-#undef DPTX_STAMP
-#undef DPTX_PP_ISSUE_W
-#undef DPTX_PP_ISSUE_A
-#undef DPTX_PP_ISSUE_A_ROWS
-#undef DPTX_PP_NEXT
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
-#endif
-}
-
-// ------------------------------------------------------------------- halo-resident 3x3 convolution
-// 3x3 / stride 1 / pad 1 convolutions on maps whose width is a multiple of 32 and height a multiple of 8 (the 1/4- and
-// 1/2-resolution maps of the decoder).  The implicit GEMM above fetches every input pixel nine times, once per tap, as part
-// of nine different A tiles; here a block owns 8 rows x 32 pixels of ONE image and 256 output channels, keeps the 10 x 34
-// input halo of a 64-channel chunk LDS-resident (43.5 KB) and runs the nine taps out of it: per 64-channel chunk the block
-// moves 43.5 KB of A and 9 x 32 KB of W through the LDS-DMA path instead of 9 x 64 KB (1.7x fewer bytes per flop).
-//
-// k order: chunk-major, taps inside a chunk = GemmParams::k_tap_fast, which launch_gemm forces for every shape this
-// kernel accepts, so that the result is bit-identical to the implicit-GEMM kernels' (small batches fall back to them).
-//
-// Same wave layout and ping-pong schedule as gemm_pp_kernel (group = 4 output rows x 32 pixels x 256 channels); group 0
-// issues the eight W pieces of the next (tap, chunk), group 1 the halo of the NEXT chunk, two of its 43 pieces per wave
-// and tap, which therefore have most of a chunk to land.
-template <int DT, bool RELU_A>
-__global__ __launch_bounds__(512, 2) void gemm_halo_kernel(const GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
-  constexpr int SLABS = TM;
-  constexpr int HC = 34, HPIX = 10 * HC, HPIECES = (HPIX + 7) / 8;  // 340 halo pixels in 43 pieces of 8 rows
-  constexpr int W_BYTES = 256 * 128, HALO_BYTES = 44 * 1024;        // 344 rows x 128 B = 44032 <= 45056
-  constexpr int HSLOTS = (HPIECES + 3) / 4;                         // pieces per wave of group 1: 11
-  extern __shared__ __attribute__((aligned(16))) char smem[];       // W x 2 | halo x 2 = 152 KB
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3, wq = wave & 3;
-  const int lr = lane & 31, lh = lane >> 5;
-  auto w_ptr = [&](int b) -> char* { return smem + b * W_BYTES; };
-  auto h_ptr = [&](int b) -> char* { return smem + 2 * W_BYTES + b * HALO_BYTES; };
-
-  const int tx_n = p.Win >> 5, tpi = tx_n * (p.Hin >> 3);
-  const int tiles_n = p.N / BN, tiles_m = (p.M / p.a_rpi) * tpi;
-  int img, y0, x0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    img = mt / tpi;
-    const int r = mt - img * tpi, ty = r / tx_n;
-    y0 = ty * 8;
-    x0 = (r - ty * tx_n) * 32;
-    n0 = nt * BN;
-  }
-  const int m_base = (img * p.Hin + y0) * p.Win + x0;
-
-  // loader offsets, one array for both roles (the groups never meet in this code):
-  //   group 1, wave wq: halo pieces id = 4 s + wq (s = 0..10); a piece is 8 halo pixels x 128 B, lane (lane>>3, lane&7)
-  //     owns chunk kc of halo pixel hp = 8 id + (lane >> 3); pixels outside the image (and the 4 rows past 339) read zeros
-  //   group 0: W rows r0 + 32 j (j = 0..7) of the 256-row tile, chunk kc (as in gemm_pp_kernel)
-  unsigned offs[HSLOTS];
-  if (wm == 1) {
-    const int kc = lane & 7;
-#pragma unroll
-    for (int s_ = 0; s_ < HSLOTS; ++s_) {
-      const int id = 4 * s_ + wq, hp = 8 * id + (lane >> 3);
-      const int hy = hp / HC, hx = hp - hy * HC;
-      const int y = y0 - 1 + hy, xx = x0 - 1 + hx;
-      const bool ok = id < HPIECES && hp < HPIX && (unsigned)y < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
-      const int sc = kc ^ ((hp >> 1) & 7);
-      const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)y * p.Win + xx) * p.a_pix_stride + sc * 8;
-      offs[s_] = ok ? (unsigned)(e * 2) : OOB;
-    }
-  } else {
-    const int t = tid & 255, kc = t & 7, r0 = t >> 3;
-    const int sc = kc ^ ((r0 >> 1) & 7);
-#pragma unroll
-    for (int j = 0; j < HSLOTS; ++j) offs[j] = j < 8 ? (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2) : 0u;
-  }
-  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
-
-  // halo pieces of slots S0, S0 + 1 (static) of the chunk at channel C0 into halo buffer DST
-#define DPTX_HALO_ISSUE_A(DST, S0, C0)                                                                             \
-  do {                                                                                                             \
-    _Pragma("unroll") for (int s_ = (S0); s_ < (S0) + 2; ++s_) {                                                   \
-      if (s_ < HSLOTS && 4 * s_ + wq < HPIECES)                                                                    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
-            rsrcA, (__attribute__((address_space(3))) void*)((DST) + (4 * s_ + wq) * 1024), 16,                    \
-            offs[s_ < HSLOTS ? s_ : 0] == OOB ? OOB : offs[s_ < HSLOTS ? s_ : 0] + (unsigned)((C0) * 2), 0, 0, 0); \
-    }                                                                                                              \
-  } while (0)
-  // the eight W pieces of (tap TAP, channel chunk C0) into W buffer DST
-#define DPTX_HALO_ISSUE_W(DST, TAP, C0)                                                                            \
-  do {                                                                                                             \
-    char* d_ = (DST) + wq * 1024;                                                                                  \
-    const unsigned wk_ = (unsigned)(((TAP) * p.Cin + (C0)) * 2);                                                   \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(d_ + 32 * j * 128), 16, \
-                                               offs[j] + wk_, 0, 0, 0);                                            \
-  } while (0)
-
-  // fragment reads: A block i = output row 4 wm + i, lane lr = pixel; tap (ky, kx) shifts the halo pixel by ky*34 + kx
-  // (the halo offsets of all nine unrolled taps are loop-invariant; left to itself hipcc hoists the 144 of them out of the
-  // chunk loop and spills -- hp0 is made opaque once per tap so that they are recomputed, ~60 VALU per 32 MFMAs)
-  int hp0 = wm * 4 * HC + lr;
-  auto read = [&](PpFrags& f, const char* hb, const char* sb, int delta, int ks) {
-    const int chunk = 2 * ks + lh;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int hp = hp0 + i * HC + delta;
-      f.a[i] = *(const u32x4_t*)(hb + hp * 128 + ((chunk ^ ((hp >> 1) & 7)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = wn * 64 + j * 32 + lr;
-      f.b[j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-    }
-  };
-  PpFrags f0, f1;
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto mma_tap = [&](const char* hb, const char* sb, int delta) {
-    asm volatile("" : "+v"(hp0));
-    read(f0, hb, sb, delta, 0);
-    read(f1, hb, sb, delta, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    pp_mma<DT, RELU_A>(f0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    read(f0, hb, sb, delta, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    pp_mma<DT, RELU_A>(f1, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    read(f1, hb, sb, delta, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    pp_mma<DT, RELU_A>(f0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    pp_mma<DT, RELU_A>(f1, acc);
-  };
-
-  const int nch = p.Cin / BK;
-  // prologue: the whole halo of chunk 0 (group 1) and W of (tap 0, chunk 0) (group 0)
-  if (wm == 0) {
-    DPTX_HALO_ISSUE_W(w_ptr(0), 0, 0);
-  } else {
-#pragma unroll
-    for (int s0 = 0; s0 < HSLOTS + 1; s0 += 2) DPTX_HALO_ISSUE_A(h_ptr(0), s0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (wm == 0) {
-    for (int cc = 0; cc < nch; ++cc) {
-      const char* hb = h_ptr(cc & 1);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int wb = (cc + tap) & 1;
-        // slot 1: W of the next (tap, chunk)
-        if (tap < 8) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), tap + 1, cc * BK);
-        else if (cc + 1 < nch) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), 0, (cc + 1) * BK);
-        asm volatile("s_barrier" ::: "memory");
-        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);        // slot 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-      }
-    }
-  } else {
-    for (int cc = 0; cc < nch; ++cc) {
-      const char* hb = h_ptr(cc & 1);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int wb = (cc + tap) & 1;
-        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);        // slot 1
-        if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's halo (issued in taps 0..5)
-        asm volatile("s_barrier" ::: "memory");
-        if (2 * tap < HSLOTS && cc + 1 < nch) DPTX_HALO_ISSUE_A(h_ptr((cc + 1) & 1), 2 * tap, (cc + 1) * BK);  // slot 2
-        asm volatile("s_barrier" ::: "memory");
-      }
-    }
-  }
-#undef DPTX_HALO_ISSUE_W
-#undef DPTX_HALO_ISSUE_A
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m_base, n0, wm, wn, lr, lh, tid, acc, p.Win);
-#endif
-}
-
-// ------------------------------------------------------------------- phased 256x256 kernel
-// Four phases per k-tile, two barriers per phase, the two wave groups (wm = 0 / 1) one barrier apart:
-//
-//     group 0:  | reads + 2 DMA pieces | 8 MFMAs | reads + 2 DMA | 8 MFMAs | ...
-//     group 1:            | 8 MFMAs | reads + 2 DMA pieces | 8 MFMAs | reads + ...
-//
-// so each SIMD always has one wave in its MFMA section while the other fetches its next fragments and issues its share of
-// the LDS-DMA (2 of the 64 one-KB pieces of a k-tile per wave and phase, instead of bursts of 12 / 4 per k-tile in
-// gemm_pp_kernel, whose fragment reads also sat in front of the MFMAs of the SAME wave).
-//
-// A k-tile is four 16-KB half-tiles: H0 = A rows 0..127, H1 = A rows 128..255, H2 = W rows 0..127, H3 = W rows 128..255.
-// Wave (wm, wn) owns rows [64 wm, +64) of H0 AND of H1, columns [32 wn, +32) of H2 AND of H3 (epilogue<ILV>), and its 4 x 2
-// accumulator blocks are visited as (top, j0), (top, j1), (bottom, j1), (bottom, j0): phase 0 reads H0 + H2, phase 1 H3,
-// phase 2 H1, phase 3 H2 again.  Tile t+1 is staged in the same order -- H0, H2, H3, H1 in phases 0..3 of tile t --
-// three (H0: four) phases before it is read, so the DMA of the two most recent steps stays in flight across the
-// barriers: every wave waits at the end of its MFMA section, group 0 with vmcnt(4), group 1 (whose wait comes one barrier
-// later) with vmcnt(2), and vmcnt(0) only in the last k-tile.  A half-tile buffer is re-staged at least two phases after
-// its last fragment read (H2: read in phase 3 of tile t-1, written in phase 1 of tile t).
-template <int DT, bool RELU_A>
-__global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
-  constexpr int SLABS = TM;
-  constexpr int HALF = 128 * 128, TILE_BYTES = 4 * HALF;  // bytes: one half-tile, one k-tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
-  int m0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    m0 = mt * BM;
-    n0 = nt * BN;
-  }
-
-  // loader: a wave-instruction moves 8 rows x 128 B; lane (r8 = lane>>3, kc = lane&7) owns chunk kc of row lrow (and of
-  // row 64 + lrow) of every half-tile.  q = 2*h + z: half h, rows z*64 + lrow.
-  const int kc = lane & 7, lrow = wave * 8 + (lane >> 3);
-  const int sc = kc ^ ((lrow >> 1) & 7);
-  int a_iy0[4], a_ix0[4];
-  unsigned a_off[4], w_off[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int m = m0 + (q >> 1) * 128 + (q & 1) * 64 + lrow;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    int rem, ox;
-    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
-    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
-    a_iy0[q] = ok ? oy * p.stride - p.pad_t : -0x40000000;
-    a_ix0[q] = ox * p.stride - p.pad_l;
-    const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[q] * p.Win + a_ix0[q]) * p.a_pix_stride + sc * 8;
-    a_off[q] = (unsigned)(ok ? e * 2 : 0);
-    w_off[q] = (unsigned)(((long long)(n0 + (q >> 1) * 128 + (q & 1) * 64 + lrow) * p.ldw + sc * 8) * 2);
-  }
-  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
-
-  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k-tile being staged (wave-uniform)
-  const int ld_base = wave * 8 * 128;
-  // the two pieces of A half H (0 / 1) resp. W half H of the k-tile at (ky, kx, c0) into buffer BUF
-#define DPTX_PH_PIECE_A(BUF, H, Z)                                                                                 \
-  do {                                                                                                             \
-    char* d_ = smem + (BUF) * TILE_BYTES + (H) * HALF + ld_base + (Z) * 64 * 128;                                  \
-    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
-    const int iy = a_iy0[2 * (H) + (Z)] + ky, ix = a_ix0[2 * (H) + (Z)] + kx;                                      \
-    const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)d_, 16,               \
-                                             valid ? a_off[2 * (H) + (Z)] + tap_ : OOB, 0, 0, 0);                  \
-  } while (0)
-#define DPTX_PH_PIECE_W(BUF, H, Z)                                                                                 \
-  do {                                                                                                             \
-    char* d_ = smem + (BUF) * TILE_BYTES + (2 + (H)) * HALF + ld_base + (Z) * 64 * 128;                            \
-    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);                                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)d_, 16,               \
-                                             w_off[2 * (H) + (Z)] + wk_, 0, 0, 0);                                 \
-  } while (0)
-#define DPTX_PH_STAGE_A(BUF, H) do { DPTX_PH_PIECE_A(BUF, H, 0); DPTX_PH_PIECE_A(BUF, H, 1); } while (0)
-#define DPTX_PH_STAGE_W(BUF, H) do { DPTX_PH_PIECE_W(BUF, H, 0); DPTX_PH_PIECE_W(BUF, H, 1); } while (0)
-#define DPTX_PH_NEXT_TAP()                                                                                         \
-  do {                                                                                                             \
-    if (p.k_tap_fast) {                                                                                            \
-      if (++kx == p.ksz) { kx = 0; if (++ky == p.ksz) { ky = 0; c0 += BK; } }                                      \
-    } else {                                                                                                       \
-      c0 += BK;                                                                                                    \
-      if (c0 >= p.Cin) { c0 = 0; if (++kx == p.ksz) { kx = 0; ++ky; } }                                            \
-    }                                                                                                              \
-  } while (0)
-
-  // fragment reads: row r of a half-tile is 128 B, chunk c at ((c ^ ((r >> 1) & 7)) << 4); the swizzle term of all of a
-  // lane's rows is (lr >> 1) & 7 (the wave offsets are multiples of 32 rows)
-  const int sw = (lr >> 1) & 7;
-  const int a_rd = (wm * 64 + lr) * 128, b_rd = (wn * 32 + lr) * 128;
-  int ch[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) ch[ks] = ((2 * ks + lh) ^ sw) << 4;
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / BK;
-  // prologue: all of tile 0
-  DPTX_PH_STAGE_A(0, 0);
-  DPTX_PH_STAGE_W(0, 0);
-  DPTX_PH_STAGE_W(0, 1);
-  DPTX_PH_STAGE_A(0, 1);
-  DPTX_PH_NEXT_TAP();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (wm == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one barrier behind
-
-#define DPTX_PH_WAIT()                                                                                             \
-  do {                                                                                                             \
-    if (!stage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-    else if (wm == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                          \
-  } while (0)
-#define DPTX_PH_MMA(I0, J, BF, HOOK0, HOOK1)                                                                       \
-  do {                                                                                                             \
-    DPTX_PH_PRIO(1);                                                                                               \
-    acc[I0][J] = T16<DT>::mfma32(af[0][0], BF[0], acc[I0][J]);                                                     \
-    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][0], BF[0], acc[I0 + 1][J]);                                             \
-    HOOK0;                                                                                                         \
-    acc[I0][J] = T16<DT>::mfma32(af[0][1], BF[1], acc[I0][J]);                                                     \
-    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][1], BF[1], acc[I0 + 1][J]);                                             \
-    acc[I0][J] = T16<DT>::mfma32(af[0][2], BF[2], acc[I0][J]);                                                     \
-    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][2], BF[2], acc[I0 + 1][J]);                                             \
-    HOOK1;                                                                                                         \
-    acc[I0][J] = T16<DT>::mfma32(af[0][3], BF[3], acc[I0][J]);                                                     \
-    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][3], BF[3], acc[I0 + 1][J]);                                             \
-    DPTX_PH_PRIO(0);                                                                                               \
-  } while (0)
-
-#ifdef DPTX_PH_NOPRIO
-#define DPTX_PH_PRIO(X) do { } while (0)
-#else
-#define DPTX_PH_PRIO(X) __builtin_amdgcn_s_setprio(X)
-#endif
-// DPTX_PH_SPLIT: 0 both DMA pieces of a phase in the load section, 1 one there and one between the MFMAs, 2 both
-// between the MFMAs (the matrix pipe keeps executing while the wave is stuck in the DMA issue)
-#ifndef DPTX_PH_SPLIT
-#define DPTX_PH_SPLIT 0
-#endif
-#define DPTX_PH_L(KIND, BUF, H) do { if (stage) { if (DPTX_PH_SPLIT == 0) DPTX_PH_STAGE_##KIND(BUF, H); else if (DPTX_PH_SPLIT == 1) DPTX_PH_PIECE_##KIND(BUF, H, 0); } } while (0)
-#define DPTX_PH_M0(KIND, BUF, H) do { if (stage && DPTX_PH_SPLIT == 2) DPTX_PH_PIECE_##KIND(BUF, H, 0); } while (0)
-#define DPTX_PH_M1(KIND, BUF, H) do { if (stage && DPTX_PH_SPLIT >= 1) DPTX_PH_PIECE_##KIND(BUF, H, 1); } while (0)
-#ifdef DPTX_PH_STAGE_FIRST   // experiment: DMA pieces in front of the fragment reads
-#define DPTX_PH_LOADS(READS, STAGE) do { STAGE; READS; } while (0)
-#else
-#define DPTX_PH_LOADS(READS, STAGE) do { READS; STAGE; } while (0)
-#endif
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool stage = kt + 1 < nk;
-    const int cb = kt & 1, nb = cb ^ 1;
-    const char* t_ = smem + cb * TILE_BYTES;
-    u32x4_t af[2][4], b0[4], b1[4];
-    // ---- phase 0: (top, j0)
-    DPTX_PH_LOADS(
-        {
-          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const u32x4_t*)(t_ + 2 * HALF + b_rd + ch[ks]);
-          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {
-            af[0][ks] = *(const u32x4_t*)(t_ + a_rd + ch[ks]);
-            af[1][ks] = *(const u32x4_t*)(t_ + a_rd + 32 * 128 + ch[ks]);
-          }
-        },
-        { DPTX_PH_L(A, nb, 0); });
-    asm volatile("s_barrier" ::: "memory");
-    if (RELU_A) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { af[0][ks] = relu8(af[0][ks]); af[1][ks] = relu8(af[1][ks]); }
-    }
-    DPTX_PH_MMA(0, 0, b0, DPTX_PH_M0(A, nb, 0), DPTX_PH_M1(A, nb, 0));
-    DPTX_PH_WAIT();
-    asm volatile("s_barrier" ::: "memory");
-    // ---- phase 1: (top, j1)
-    DPTX_PH_LOADS({ _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b1[ks] = *(const u32x4_t*)(t_ + 3 * HALF + b_rd + ch[ks]); },
-                  { DPTX_PH_L(W, nb, 0); });
-    asm volatile("s_barrier" ::: "memory");
-    DPTX_PH_MMA(0, 1, b1, DPTX_PH_M0(W, nb, 0), DPTX_PH_M1(W, nb, 0));
-    DPTX_PH_WAIT();
-    asm volatile("s_barrier" ::: "memory");
-    // ---- phase 2: (bottom, j1)
-    DPTX_PH_LOADS(
-        {
-          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {
-            af[0][ks] = *(const u32x4_t*)(t_ + HALF + a_rd + ch[ks]);
-            af[1][ks] = *(const u32x4_t*)(t_ + HALF + a_rd + 32 * 128 + ch[ks]);
-          }
-        },
-        { DPTX_PH_L(W, nb, 1); });
-    asm volatile("s_barrier" ::: "memory");
-    if (RELU_A) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { af[0][ks] = relu8(af[0][ks]); af[1][ks] = relu8(af[1][ks]); }
-    }
-    DPTX_PH_MMA(2, 1, b1, DPTX_PH_M0(W, nb, 1), DPTX_PH_M1(W, nb, 1));
-    DPTX_PH_WAIT();
-    asm volatile("s_barrier" ::: "memory");
-    // ---- phase 3: (bottom, j0)
-    DPTX_PH_LOADS({ _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const u32x4_t*)(t_ + 2 * HALF + b_rd + ch[ks]); },
-                  { DPTX_PH_L(A, nb, 1); });
-    asm volatile("s_barrier" ::: "memory");
-    DPTX_PH_MMA(2, 0, b0, DPTX_PH_M0(A, nb, 1), DPTX_PH_M1(A, nb, 1));
-    if (stage) DPTX_PH_NEXT_TAP();
-    DPTX_PH_WAIT();
-    asm volatile("s_barrier" ::: "memory");
-  }
-  if (wm == 0) asm volatile("s_barrier" ::: "memory");  // group 0 catches up
-#undef DPTX_PH_MMA
-#undef DPTX_PH_WAIT
-#undef DPTX_PH_LOADS
-#undef DPTX_PH_PRIO
-#undef DPTX_PH_NEXT_TAP
-#undef DPTX_PH_STAGE_W
-#undef DPTX_PH_STAGE_A
-#undef DPTX_PH_PIECE_W
-#undef DPTX_PH_PIECE_A
-#undef DPTX_PH_L
-#undef DPTX_PH_M0
-#undef DPTX_PH_M1
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS, true>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
-#endif
-}
-
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_FP32>
-__global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-  constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
-  constexpr int A_REGS = A_FP32 ? 2 : 1;
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  // block -> tile: XCD x = blockIdx % 8 (observed dispatch placement; only speed depends on it) owns the
-  // (x / xcd_n)-th m-slice and (x % xcd_n)-th n-slice of the tile grid; inside a slice n runs fastest so
-  // consecutive blocks of one XCD share their A rows.
-  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
-  int m0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    m0 = mt * BM;
-    n0 = nt * BN;
-  }
-
-  const int kc = tid & 7, r0 = tid >> 3;
-  const bool big_m = p.M >= (1 << 23);
-  int a_iy0[A_PASSES], a_ix0[A_PASSES];
-  long long a_base[A_PASSES];
-#pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + r0 + 32 * i;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    int rem, ox;
-    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, big_m, rem);
-    const int oy = row_div(rem, p.Wout, p.wout_rcp, big_m, ox);
-    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
-    a_ix0[i] = ox * p.stride - p.pad_l;
-    a_base[i] = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + kc * 8;
-  }
-  const char* __restrict__ Ab = (const char*)p.A;
-  const uint16_t* __restrict__ Wb = (const uint16_t*)p.W;
-  long long w_off[B_PASSES];
-#pragma unroll
-  for (int j = 0; j < B_PASSES; ++j) w_off[j] = (long long)(n0 + r0 + 32 * j) * p.ldw + kc * 8;
-
-  u32x4_t ra[A_PASSES * A_REGS];
-  u32x4_t rb[B_PASSES];
-  int ky = 0, kx = 0, c0 = 0;
-  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-
-#define DPTX_LOAD_TILE(K0)                                                                           \
-  do {                                                                                               \
-    const long long tap_ = (long long)(ky * p.Win + kx) * p.a_pix_stride + c0;                       \
-    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                           \
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                              \
-      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);       \
-      const long long e = a_base[i] + tap_;                                                          \
-      if constexpr (A_FP32) {                                                                        \
-        u32x4_t lo = zero4, hi = zero4;                                                              \
-        if (valid) {                                                                                 \
-          const u32x4_t* src = (const u32x4_t*)(Ab + e * 4);                                         \
-          lo = src[0];                                                                               \
-          hi = src[1];                                                                               \
-        }                                                                                            \
-        ra[2 * i] = lo;                                                                              \
-        ra[2 * i + 1] = hi;                                                                          \
-      } else {                                                                                       \
-        u32x4_t v = zero4;                                                                           \
-        if (valid) v = *(const u32x4_t*)(Ab + e * 2);                                                \
-        ra[i] = v;                                                                                   \
-      }                                                                                              \
-    }                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) rb[j] = *(const u32x4_t*)(Wb + w_off[j] + (K0)); \
-    c0 += BK;                                                                                        \
-    if (c0 >= p.Cin) {                                                                               \
-      c0 = 0;                                                                                        \
-      if (++kx == p.ksz) { kx = 0; ++ky; }                                                           \
-    }                                                                                                \
-  } while (0)
-
-#define DPTX_STORE_TILE(BUF)                                                                         \
-  do {                                                                                               \
-    char* sa_ = smem + (BUF) * STAGE_BYTES;                                                          \
-    char* sb_ = sa_ + BM * 128;                                                                      \
-    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                           \
-      const int row = r0 + 32 * i;                                                                   \
-      u32x4_t v;                                                                                     \
-      if constexpr (A_FP32) {                                                                        \
-        const u32x4_t lo = ra[2 * i], hi = ra[2 * i + 1];                                            \
-        v.x = T16<DT>::pack2(__uint_as_float(lo.x), __uint_as_float(lo.y));                          \
-        v.y = T16<DT>::pack2(__uint_as_float(lo.z), __uint_as_float(lo.w));                          \
-        v.z = T16<DT>::pack2(__uint_as_float(hi.x), __uint_as_float(hi.y));                          \
-        v.w = T16<DT>::pack2(__uint_as_float(hi.z), __uint_as_float(hi.w));                          \
-      } else {                                                                                       \
-        v = ra[i];                                                                                   \
-      }                                                                                              \
-      if (p.a_relu) v = relu8(v);                                                                    \
-      *(u32x4_t*)(sa_ + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = v;                             \
-    }                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < B_PASSES; ++j) {                                           \
-      const int row = r0 + 32 * j;                                                                   \
-      *(u32x4_t*)(sb_ + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rb[j];                         \
-    }                                                                                                \
-  } while (0)
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / BK;
-  DPTX_LOAD_TILE(0);
-  DPTX_STORE_TILE(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) DPTX_LOAD_TILE((kt + 1) * BK);
-    const char* sa = smem + (kt & 1) * STAGE_BYTES;
-    mma_tile<DT, TM, TN, false, 1>(sa, sa + BM * 128, 0, 0, wm, wn, lr, lh, acc);
-    if (more) DPTX_STORE_TILE((kt + 1) & 1);
-    __syncthreads();
-  }
-#undef DPTX_LOAD_TILE
-#undef DPTX_STORE_TILE
-  epilogue<DT, BM, BN, TM, TN>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
-}
-
-// --------------------------------------------------------------------------------- dispatch
-template <int BM, int BN, int PL>
-constexpr size_t gemm_smem_bytes() {
-  constexpr size_t stage = 2 * (size_t)PL * (BM + BN) * 128;
-  constexpr size_t ct_full = (size_t)BM * (BN + 4) * 4;
-  constexpr size_t ct = ct_full > 160 * 1024 ? (size_t)64 * (BN + 4) * 4 : ct_full;  // slab epilogue (2 wave rows x 32)
-  return stage > ct ? stage : ct;
-}
-
-template <typename K>
-static void set_smem_attr(K k, size_t smem) {
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-}
-
-// A/B experiments: DPTX_GEMM=reg forces the register-staged kernel; DPTX_XCD=0 disables the 2-D XCD
-// partition of the tile grid.
-static int gemm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* s = getenv("DPTX_GEMM");
-    v = (s && s[0] == 'r') ? 1 : 0;
-  }
-  return v;
-}
-static int xcd_partition_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* s = getenv("DPTX_XCD");
-    v = (s && s[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
-// Chooses the XCD grid (xm x xn, xm*xn = 8) for a tile grid: XCD (xi, xj) owns the m-tiles of slice xi
-// and the n-tiles of slice xj, so per XCD only A/xm and W/xn are touched.  Objective: HBM/MALL-side
-// traffic xn*A_bytes + xm*W_bytes, subject to the XCD's W slice fitting comfortably in its 4 MB L2
-// (otherwise W is re-fetched for every m-tile) and xn dividing the n-tile count.
-static void choose_xcd_grid(const GemmParams& p, int tiles_m, int tiles_n, int& xm, int& xn) {
-  xm = 8; xn = 1;
-  if (!xcd_partition_enabled()) return;
-  const double a_bytes = (double)p.M * p.K * 2.0, w_bytes = (double)p.N * p.K * 2.0;
-  double best = -1.0;
-  const int cand[4] = {1, 2, 4, 8};
-  for (int c = 0; c < 4; ++c) {
-    const int n = cand[c], m = 8 / n;
-    if (tiles_n % n != 0 || tiles_m < m) continue;
-    const double w_slice = w_bytes / n;
-    double cost = n * a_bytes + m * w_bytes;
-    if (w_slice > 2.0e6) cost += (double)tiles_m / m * w_slice * 8.0;  // L2 thrash: W slice re-read per m-tile
-    if (best < 0.0 || cost < best) { best = cost; xm = m; xn = n; }
-  }
-}
-
-template <int DT, int PL, int BM, int BN, int WM_, int WN_>
-static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-  GemmParams q = p;
-  choose_xcd_grid(p, tiles_m, tiles_n, q.xcd_m, q.xcd_n);
-  const int tiles = 8 * ((tiles_m + q.xcd_m - 1) / q.xcd_m) * (tiles_n / q.xcd_n);
-  constexpr size_t smem = gemm_smem_bytes<BM, BN, PL>();
-  const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && (long long)p.N * p.ldw * 2 < (1ll << 31) &&
-                       p.M < (1 << 23);
-  if (PL == 2 && !glds_ok) return hipErrorInvalidValue;  // the 3-pass mode exists only on the direct-to-LDS path
-  if constexpr (DT != DT_FP8 && PL == 1 && BM == 256 && BN == 256) {
-    static int pp = -1;  // ping-pong schedule of the two wave groups (gemm_pp_kernel); DPTX_PP=0: the lockstep loop (A/B runs)
-    if (pp < 0) { const char* t = getenv("DPTX_PP"); pp = t ? atoi(t) : 1; }
-    if (pp == 2 && glds_ok) {
-      if (p.a_relu) {
-        auto k = gemm_ph_kernel<DT, true>;
-        static bool done = false;
-        if (!done) { set_smem_attr(k, smem); done = true; }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
-      } else {
-        auto k = gemm_ph_kernel<DT, false>;
-        static bool done = false;
-        if (!done) { set_smem_attr(k, smem); done = true; }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
-      }
-      return hipGetLastError();
-    }
-    if (pp && glds_ok) {
-      // pp == 3: three LDS buffers for A rows 128..255 (144 KB)
-      auto go = [&](auto k, size_t bytes) {
-        static bool done = false;
-        if (!done) { set_smem_attr(k, bytes); done = true; }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), bytes, stream, q);
-      };
-      constexpr size_t smem3 = 144 * 1024;
-      if (pp == 3) {
-        if (p.a_relu) go(gemm_pp_kernel<DT, true, 1>, smem3);
-        else go(gemm_pp_kernel<DT, false, 1>, smem3);
-      } else if (pp == 4) {  // group 0 issues all sixteen pieces and pre-reads its first fragments
-        if (p.a_relu) go(gemm_pp_kernel<DT, true, 2>, smem);
-        else go(gemm_pp_kernel<DT, false, 2>, smem);
-      } else {
-        if (p.a_relu) go(gemm_pp_kernel<DT, true, 0>, smem);
-        else go(gemm_pp_kernel<DT, false, 0>, smem);
-      }
-      return hipGetLastError();
-    }
-  }
-  if constexpr (DT == DT_FP8) {  // fp8 operands: direct-to-LDS path only, pre-activation is the producer's job
-    if (!glds_ok || p.a_relu) return hipErrorInvalidValue;
-    auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
-    static bool done = false;
-    if (!done) { set_smem_attr(k, smem); done = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
-    return hipGetLastError();
-  } else
-  if (glds_ok && (PL == 2 || gemm_variant() != 1)) {
-    if (p.a_relu) {
-      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL>;
-      static bool done = false;
-      if (!done) { set_smem_attr(k, smem); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
-    } else {
-      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
-      static bool done = false;
-      if (!done) { set_smem_attr(k, smem); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
-    }
-  } else if constexpr (WM_ * WN_ != 4) {
-    return hipErrorInvalidValue;  // the 8-wave tile exists only on the direct-to-LDS path
-  } else if constexpr (PL == 1) {
-    constexpr size_t smem1 = gemm_smem_bytes<BM, BN, 1>();
-    if (p.a_fp32) {
-      auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, true>;
-      static bool done = false;
-      if (!done) { set_smem_attr(k, smem1); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, q);
-    } else {
-      auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, false>;
-      static bool done = false;
-      if (!done) { set_smem_attr(k, smem1); done = true; }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, q);
-    }
-  }
-  return hipGetLastError();
-}
-
-// Shapes gemm_halo_kernel accepts: 3x3 / stride 1 / pad 1 on a dense NHWC map whose width is a multiple of 32 and height a
-// multiple of 8, Cin % 64 == 0, N % 256 == 0, 16-bit operands, no GroupNorm statistics.  launch_gemm forces k_tap_fast for
-// them whichever kernel ends up running, so that the k order -- and with it every bit of the result -- is the same.
-static bool halo_shape(const GemmParams& p) {
-  // Measured (profiles/r02_experiments.md): 917 vs 949 TF/s on rcu@96 -- the 1.7x fewer DMA bytes do not pay, the loop is
-  // bound by the ping-pong structure (one group's 32 MFMAs + first-read latency + barrier per slot), not by operand
-  // traffic.  Off unless DPTX_HALO=1.
-  static int on = -1;
-  if (on < 0) { const char* t = getenv("DPTX_HALO"); on = (t && t[0] == '1') ? 1 : 0; }
-  return on && p.ksz == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.Wout == p.Win && p.a_rpi == p.Hin * p.Win &&
-         p.Win % 32 == 0 && p.Hin % 8 == 0 && p.Cin % 64 == 0 && p.N % 256 == 0 && p.K == 9 * p.Cin && !p.a_fp32 &&
-         p.gn_part == nullptr && p.M % p.a_rpi == 0 && p.c_rpi == 0x7fffffff && p.a_bytes > 0 && p.a_bytes < (1ll << 31) &&
-         (long long)p.N * p.ldw * 2 < (1ll << 31);
-}
-
-template <int DT>
-static hipError_t launch_halo(const GemmParams& p, hipStream_t stream) {
-  const int tiles_m = (p.M / p.a_rpi) * (p.Win / 32) * (p.Hin / 8), tiles_n = p.N / 256;
-  GemmParams q = p;
-  choose_xcd_grid(p, tiles_m, tiles_n, q.xcd_m, q.xcd_n);
-  const int tiles = 8 * ((tiles_m + q.xcd_m - 1) / q.xcd_m) * (tiles_n / q.xcd_n);
-  constexpr size_t smem = 2 * 32 * 1024 + 2 * 44 * 1024;
-  auto go = [&](auto k) {
-    static bool done = false;
-    if (!done) { set_smem_attr(k, smem); done = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
-  };
-  if (p.a_relu) go(gemm_halo_kernel<DT, true>);
-  else go(gemm_halo_kernel<DT, false>);
-  return hipGetLastError();
-}
-
-template <int DT, int PL>
-static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
-  // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
-  const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
-  static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (experiments)
-  if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
-  {
-    if (forced == 128128 && p.N % 128 == 0) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
-    if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
-    if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
-  }
-  // 256x256 (8 waves, 1 block/CU; 16-bit modes: the ping-pong kernel): half the DMA issues and 3/4 of the LDS reads per MFMA
-  // of the 128x128 tile, but no second block to hide prologue/epilogue and a coarser tail.  Chosen when its estimated
-  // efficiency wins: fill of the last round of CUs (256 slots) x 1.25 (the measured per-tile advantage at K >= 512 with the
-  // pipelined fragment reads, profiles/r02_experiments.md) against the fill of the 128x128 grid (512 slots).  That picks
-  // it for the ViT GEMMs, patch-embed and the 3x3 convs at 1/4 resolution and keeps 128x128 for the small maps.
-  if constexpr (PL == 1 && DT != DT_FP8) {
-    // 3x3 convolutions on the large decoder maps: LDS-resident input halo (from 200 tiles up; below that the implicit
-    // GEMM's smaller tiles fill the chip better, and give the same bits)
-    if (halo_shape(p) && forced == 0 && (long long)(p.M / p.a_rpi) * (p.Win / 32) * (p.Hin / 8) * (p.N / 256) >= 200)
-      return launch_halo<DT>(p, stream);
-  }
-  if constexpr (PL == 1) {
-    const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
-    static int min_k = -1;  // DPTX_T256_MINK: shortest K that takes the 256x256 tile (experiments)
-    if (min_k < 0) { const char* t = getenv("DPTX_T256_MINK"); min_k = t ? atoi(t) : 512; }
-    if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= min_k) {
-      const long long t256 = m256 * (p.N / 256), r256 = (t256 + 255) / 256;
-      const long long t128 = m128 * (p.N / 128), r128 = (t128 + 511) / 512;
-      const double fill256 = (double)t256 / (double)(r256 * 256), fill128 = (double)t128 / (double)(r128 * 512);
-      static double adv = -1.0;  // DPTX_T256_ADV: per-tile advantage of the 256x256 kernel assumed by the rule (experiments)
-      if (adv < 0.0) { const char* t = getenv("DPTX_T256_ADV"); adv = t ? atof(t) : 1.25; }
-      if (t256 >= 200 && fill256 * adv >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
-    }
-  }
-  if constexpr (PL == 2) {
-    // 3-MFMA modes are one block per CU (two planes of two stages = 128 KB of LDS); eight waves (2 x 4, wave tile
-    // 64 x 32) instead of four put two waves on every SIMD, so that one's fragment reads overlap the other's MFMAs:
-    // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md).  DPTX_X3_W8=0: four waves.
-    static int w8 = -1;
-    if (w8 < 0) { const char* t = getenv("DPTX_X3_W8"); w8 = t ? atoi(t) : 1; }
-    if (w8 && p.N % 128 == 0 && m128 * (p.N / 128) >= 200) return launch_cfg<DT, PL, 128, 128, 2, 4>(p, stream);
-  }
-  // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
-  // 128x64 by 2..10 %, whose second round is nearly empty
-  if (p.N % 128 == 0 && m128 * (p.N / 128) >= 256) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
-  if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1>(p, stream);
-  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 256, 64, 4, 1>(p, stream);
-  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
-  if (p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
-  return hipErrorInvalidValue;
+hipError_t launch_gemm_16(int dt, const GemmParams& p, hipStream_t stream) {
+  return dt == DT_BF16 ? launch_dt<DT_BF16, 1>(p, stream) : launch_gemm_fp16(p, stream);
 }
 
 void gemm_params_dense(GemmParams& p, int M, int N, int K) {
@@ -1651,14 +30,14 @@ hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
   if (mode == MODE_FP8) {  // 128 e4m3 per k-tile row
     if (p.K % 128 != 0 || p.Cin % 128 != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 16 != 0 || p.gn_part != nullptr)
       return hipErrorInvalidValue;
-    return launch_dt<DT_FP8, 1>(p, stream);
+    return launch_gemm_fp8(p, stream);
   }
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 8 != 0) return hipErrorInvalidValue;
   if (halo_shape(p)) p.k_tap_fast = 1;  // one k order for these shapes, whichever kernel runs them (all modes)
-  if (mode == MODE_BF16) return launch_dt<DT_BF16, 1>(p, stream);
-  if (mode == MODE_FP16) return launch_dt<DT_FP16, 1>(p, stream);
-  if (mode == MODE_BF16X3) return launch_dt<DT_BF16, 2>(p, stream);
-  if (mode == MODE_FP16X3) return launch_dt<DT_FP16, 2>(p, stream);
+  if (mode == MODE_BF16) return launch_gemm_16(DT_BF16, p, stream);
+  if (mode == MODE_FP16) return launch_gemm_16(DT_FP16, p, stream);
+  if (mode == MODE_BF16X3) return launch_gemm_x3(DT_BF16, p, stream);
+  if (mode == MODE_FP16X3) return launch_gemm_x3(DT_FP16, p, stream);
   return hipErrorInvalidValue;
 }
 
