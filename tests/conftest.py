@@ -16,7 +16,7 @@ def pytest_configure(config):
 # then end-to-end / golden / other sizes / pre-post-processing), comparisons of the engine with ITSELF (determinism,
 # fused-vs-unfused, stream schedules, dual-vs-single, CLI plumbing) last -- with `-x`, a failing self-comparison can no
 # longer hide the parity evidence.
-_FILE_RANK = ["test_gpu_ops.py", "test_gpu_x3.py", "test_gpu_mixed.py", "test_gpu_e2e.py", "test_gpu_flex.py",
+_FILE_RANK = ["test_gpu_ops.py", "test_gpu_x3.py", "test_gpu_mixed.py", "test_gpu_e2e.py", "test_gpu_vitl16.py", "test_gpu_flex.py",
               "test_gpu_prepost.py", "test_gpu_fp8.py", "test_gpu_dual.py", "test_gpu_cli.py", "test_gpu_stress.py"]
 _SELF_COMPARISONS = ("deterministic", "fused_head_equals", "two_stream", "packed_blob", "bitwise", "bit_identical", "stress",
                      "input_contract")
@@ -30,6 +30,14 @@ def pytest_collection_modifyitems(session, config, items):
         return (1 if is_self else 0, rank)
 
     items.sort(key=key)  # stable: the order inside a file is kept
+    # the opt-in halo convolution is selected by an environment variable that the library reads once per process: its
+    # parametrized cases run in the child process of test_conv_halo_resident_in_child (DPTX_HALO=1), not in this one
+    if os.environ.get("DPTX_HALO") != "1":
+        keep = [it for it in items if not it.name.startswith("test_conv_halo_resident[")]
+        dropped = [it for it in items if it.name.startswith("test_conv_halo_resident[")]
+        if dropped:
+            config.hook.pytest_deselected(items=dropped)
+            items[:] = keep
 
 
 @pytest.fixture(scope="session")

@@ -108,8 +108,7 @@ def test_conv_halo_resident(dtype, case):
     """gemm_halo_kernel (LDS-resident input halo; an experiment that is only selected with DPTX_HALO=1, so this test runs
     it in a child process): against the fp32 convolution, and bit for bit against the implicit-GEMM kernels, which run
     the same shape when the batch is too small for it (launch_gemm gives both the same k order)."""
-    if os.environ.get("DPTX_HALO") != "1":
-        pytest.skip("runs inside test_conv_halo_resident_in_child (DPTX_HALO=1)")
+    assert os.environ.get("DPTX_HALO") == "1"  # tests/conftest.py deselects these cases otherwise
     B, H, W, Cin, Cout, a_relu, act, res = case
     X = rnd(B, H, W, Cin, dtype=dtype, seed=16)
     Wt = rnd(Cout, 3, 3, Cin, dtype=dtype, scale=(9 * Cin) ** -0.5, seed=17)
