@@ -170,3 +170,25 @@ def test_bf16x3_packing_has_hi_and_lo_planes(built_lib):
     # fp32 vectors live only in the hi half
     o, b = offs["pretrained.model.pos_embed"]
     assert not b3[b1.size + o: b1.size + o + b].any()
+
+
+def test_vitl16_host_packing(built_lib):
+    """DPT-Large behind the same ABI (dptx_config.backbone): strict loading of the vitl16 key set, and the ConvTranspose2d
+    weights of reassemble stages 1 / 2 packed as the GEMM operand [(dy*k + dx)*Cout + co][ci] (engine.hip R_DECONV)."""
+    from omnidata_amd.engine import Engine
+    sd = random_state_dict(3, 1, backbone="vitl16_384")
+    e = Engine(num_channels=1, max_batch=1, dtype="bf16", device_id=None, backbone="vitl16_384")
+    with pytest.raises(RuntimeError, match="unexpected key"):
+        e.load_state_dict({"pretrained.model.patch_embed.backbone.stem.conv.weight": torch.zeros(64, 3, 7, 7)})  # a hybrid key
+    e.load_state_dict(sd)
+    blob = e.export_packed_host().tobytes()
+    for n, k in ((1, 4), (2, 2)):
+        w = sd[f"pretrained.act_postprocess{n}.4.weight"]            # [Cin, Cout, k, k]
+        want = w.permute(2, 3, 1, 0).reshape(k * k * w.shape[1], w.shape[0]).contiguous()   # [(dy, dx, co)][ci]
+        pos = blob.find(want.to(torch.bfloat16).view(torch.int16).numpy().tobytes())
+        assert pos >= 0 and pos % 256 == 0, n
+        b = sd[f"pretrained.act_postprocess{n}.4.bias"]
+        assert blob.find(b.repeat(k * k).numpy().tobytes()) >= 0     # the bias, once per (dy, dx)
+    e.close()
+    with pytest.raises(RuntimeError):
+        Engine(num_channels=3, max_batch=1, device_id=None, backbone="vitl16_384", dual=True)   # the dual-task model is the hybrid
