@@ -657,10 +657,15 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 // group 0's vmcnt(0) and the barrier behind its MFMA slot have passed -- which lets group 0 fetch the first fragments of
 // its next MFMA slot BEFORE the barrier in front of that slot (the ~200 cycles of read latency the slot trace shows at
 // the head of every MFMA slot disappear from one of the two).
+//
+// VAR == 3 (OVL): ONE barrier per k-tile and overlapping MFMA slots.  Three LDS buffers for A rows 0..127 (144 KB): group 1
+// multiplies first and then issues its four pieces for tile kt+2, so that everything of tile kt is complete when iteration
+// kt starts -- group 0 issues its twelve pieces for tile kt+1 and goes straight into its own MFMAs of tile kt, without
+// waiting for group 1 to finish; both groups meet at the single barrier at the end of the iteration.
 template <int DT, bool RELU_A, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr bool A3 = VAR == 1, G0ALL = VAR == 2;
+  constexpr bool A3 = VAR == 1, G0ALL = VAR == 2, OVL = VAR == 3;
   constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
   constexpr int SLABS = TM;
   constexpr int HALF = 128 * 128;  // bytes of a 128-row operand tile
@@ -672,9 +677,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   const int lr = lane & 31, lh = lane >> 5;
   // LDS map.  !A3: stage b = [A rows 0..127 | A rows 128..255 | W rows 0..255] at b * 64 KB.
   //            A3: W x 2 at 0, A rows 0..127 x 2 at 64 KB, A rows 128..255 x 3 at 96 KB.
-  auto w_ptr = [&](int b) -> char* { return smem + (A3 ? b * 2 * HALF : b * 4 * HALF + 2 * HALF); };
-  auto alo_ptr = [&](int b) -> char* { return smem + (A3 ? 4 * HALF + b * HALF : b * 4 * HALF); };
-  auto ahi_ptr = [&](int h) -> char* { return smem + (A3 ? 6 * HALF + h * HALF : h * 4 * HALF + HALF); };
+  //           OVL: W x 2 at 0, A rows 128..255 x 2 at 64 KB, A rows 0..127 x 3 at 96 KB.
+  auto w_ptr = [&](int b) -> char* { return smem + ((A3 || OVL) ? b * 2 * HALF : b * 4 * HALF + 2 * HALF); };
+  auto alo_ptr = [&](int b) -> char* { return smem + (OVL ? 6 * HALF + b * HALF : A3 ? 4 * HALF + b * HALF : b * 4 * HALF); };
+  auto ahi_ptr = [&](int h) -> char* { return smem + (OVL ? 4 * HALF + h * HALF : A3 ? 6 * HALF + h * HALF : h * 4 * HALF + HALF); };
 
   const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
   int m0, n0;
@@ -784,12 +790,46 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     if (A3 && nk > 1) DPTX_PP_ISSUE_A(ahi_ptr(1));
   } else if (!G0ALL) {
     DPTX_PP_ISSUE_A(alo_ptr(0));
+    if (OVL && nk > 1) DPTX_PP_ISSUE_A(alo_ptr(1));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
   // that hipcc resolves with copies: 500 spilled registers)
   PpFrags f0, f1;
+  if constexpr (OVL) {
+    if (wm == 0) {
+      int h3 = 0;  // buffer of A rows 0..127 of tile kt
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+          DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
+          DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));
+        }
+        const char* sa = alo_ptr(h3);
+        const char* sb = w_ptr(kt & 1);
+        h3 = h3 == 2 ? 0 : h3 + 1;
+        pp_read(f0, sa, sb, wn, lr, lh, 0);
+        pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1's W and A rows 128..255 have landed
+        asm volatile("s_barrier" ::: "memory");
+      }
+    } else {
+      int h3 = 2;  // buffer of A rows 0..127 of tile kt + 2
+      for (int kt = 0; kt < nk; ++kt) {
+        const char* sa = ahi_ptr(kt & 1);
+        const char* sb = w_ptr(kt & 1);
+        pp_read(f0, sa, sb, wn, lr, lh, 0);
+        pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
+        const bool more = kt + 2 < nk;
+        if (more) DPTX_PP_ISSUE_A(alo_ptr(h3));
+        h3 = h3 == 2 ? 0 : h3 + 1;
+        // A rows 0..127 of tile kt+1 (issued an iteration ago) have landed; the four pieces just issued may fly
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+      }
+    }
+  } else
   if (wm == 0) {
     int h_wr = 2;  // A3: buffer of A rows 128..255 of tile kt + 2
     for (int kt = 0; kt < nk; ++kt) {
@@ -1503,6 +1543,10 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
         } else if (pp == 4) {  // group 0 issues all sixteen pieces and pre-reads its first fragments
           if (p.a_relu) go(gemm_pp_kernel<DT, true, 2>, smem);
           else go(gemm_pp_kernel<DT, false, 2>, smem);
+          done_ = true;
+        } else if (pp == 5) {  // one barrier per k-tile, overlapping MFMA slots
+          if (p.a_relu) go(gemm_pp_kernel<DT, true, 3>, smem3);
+          else go(gemm_pp_kernel<DT, false, 3>, smem3);
           done_ = true;
         }
       }
