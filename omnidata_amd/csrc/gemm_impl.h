@@ -617,6 +617,21 @@ __device__ __forceinline__ void pp_mma(PpFrags& f, f32x16_t (&acc)[4][2]) {
 template <int DT, bool RELU_A>
 __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char* sa, const char* sb, int wn, int lr, int lh,
                                             f32x16_t (&acc)[4][2]) {
+#if defined(DPTX_PP_PROBE) && DPTX_PP_PROBE == 2   // timing probe (wrong results): DMA and barriers only
+  return;
+#endif
+#ifdef DPTX_PP_FEWREADS  // timing probe (wrong results): k-steps 1..3 re-use the fragments of k-step 0 -- 6 reads instead of 24
+  f1 = f0;
+  __builtin_amdgcn_sched_barrier(0);
+  pp_mma<DT, false>(f0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_mma<DT, false>(f1, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_mma<DT, false>(f0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  pp_mma<DT, false>(f1, acc);
+  return;
+#endif
   pp_read(f1, sa, sb, wn, lr, lh, 1);
   __builtin_amdgcn_sched_barrier(0);
   pp_mma<DT, RELU_A>(f0, acc);
@@ -662,10 +677,14 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 // multiplies first and then issues its four pieces for tile kt+2, so that everything of tile kt is complete when iteration
 // kt starts -- group 0 issues its twelve pieces for tile kt+1 and goes straight into its own MFMAs of tile kt, without
 // waiting for group 1 to finish; both groups meet at the single barrier at the end of the iteration.
+//
+// VAR == 4 (OVL2): the same with the DMA split 8 / 8: group 0 issues only the W pieces of tile kt+1 (in front of its
+// MFMAs), group 1 -- which idles at the barrier for ~900 cycles in VAR 3 -- issues ALL of A of tile kt+2 behind its MFMAs.
+// Three buffers for both A halves, two for W: 160 KB, the whole LDS.
 template <int DT, bool RELU_A, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr bool A3 = VAR == 1, G0ALL = VAR == 2, OVL = VAR == 3;
+  constexpr bool A3 = VAR == 1, G0ALL = VAR == 2, OVL = VAR == 3, OVL2 = VAR == 4;
   constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
   constexpr int SLABS = TM;
   constexpr int HALF = 128 * 128;  // bytes of a 128-row operand tile
@@ -678,9 +697,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   // LDS map.  !A3: stage b = [A rows 0..127 | A rows 128..255 | W rows 0..255] at b * 64 KB.
   //            A3: W x 2 at 0, A rows 0..127 x 2 at 64 KB, A rows 128..255 x 3 at 96 KB.
   //           OVL: W x 2 at 0, A rows 128..255 x 2 at 64 KB, A rows 0..127 x 3 at 96 KB.
-  auto w_ptr = [&](int b) -> char* { return smem + ((A3 || OVL) ? b * 2 * HALF : b * 4 * HALF + 2 * HALF); };
-  auto alo_ptr = [&](int b) -> char* { return smem + (OVL ? 6 * HALF + b * HALF : A3 ? 4 * HALF + b * HALF : b * 4 * HALF); };
-  auto ahi_ptr = [&](int h) -> char* { return smem + (OVL ? 4 * HALF + h * HALF : A3 ? 6 * HALF + h * HALF : h * 4 * HALF + HALF); };
+  //          OVL2: W x 2 at 0, A rows 0..127 x 3 at 64 KB, A rows 128..255 x 3 at 112 KB.
+  auto w_ptr = [&](int b) -> char* { return smem + ((A3 || OVL || OVL2) ? b * 2 * HALF : b * 4 * HALF + 2 * HALF); };
+  auto alo_ptr = [&](int b) -> char* {
+    return smem + (OVL2 ? 4 * HALF + b * HALF : OVL ? 6 * HALF + b * HALF : A3 ? 4 * HALF + b * HALF : b * 4 * HALF);
+  };
+  auto ahi_ptr = [&](int h) -> char* {
+    return smem + (OVL2 ? 7 * HALF + h * HALF : OVL ? 4 * HALF + h * HALF : A3 ? 6 * HALF + h * HALF : h * 4 * HALF + HALF);
+  };
 
   const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
   int m0, n0;
@@ -700,12 +724,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   const int kc = t & 7, r0 = t >> 3;
   const int sc = kc ^ ((r0 >> 1) & 7);
   const int a_row0 = wm == 0 ? 128 : 0;
-  constexpr int NA = G0ALL ? 8 : 4;  // G0ALL: i = 4..7 are A rows 0..127, loaded by group 0 as well
+  // G0ALL: i = 4..7 are A rows 0..127, loaded by group 0 as well; OVL2: i = 4..7 are A rows 128..255, loaded by group 1
+  constexpr int NA = (G0ALL || OVL2) ? 8 : 4;
   int a_iy0[NA], a_ix0[NA];
   unsigned a_off[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int m = m0 + (i < 4 ? a_row0 + r0 + 32 * i : r0 + 32 * (i - 4));
+    const int m = m0 + (i < 4 ? a_row0 + r0 + 32 * i : (OVL2 ? 128 : 0) + r0 + 32 * (i - 4));
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
     int rem, ox;
@@ -763,6 +788,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     DPTX_PP_NEXT(kyw, kxw, c0w);                                                                                   \
   } while (0)
 
+#if defined(DPTX_PP_PROBE) && DPTX_PP_PROBE == 1   // timing probe (wrong results): no DMA inside the k-loop
+#define DPTX_PP_LOOP_ISSUE_W(DST) do { } while (0)
+#define DPTX_PP_LOOP_ISSUE_A(DST) do { } while (0)
+#else
+#define DPTX_PP_LOOP_ISSUE_W(DST) DPTX_PP_ISSUE_W(DST)
+#define DPTX_PP_LOOP_ISSUE_A(DST) DPTX_PP_ISSUE_A(DST)
+#endif
   f32x16_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -783,7 +815,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
 #endif
   // prologue: tile 0 (A3: also A rows 128..255 of tile 1)
-  if (wm == 0) {
+  if (OVL2) {
+    if (wm == 0) {
+      DPTX_PP_ISSUE_W(w_ptr(0));
+    } else {
+      DPTX_PP_ISSUE_A_ROWS(ahi_ptr(0), NA - 4);
+      DPTX_PP_ISSUE_A(alo_ptr(0));
+      if (nk > 1) {
+        DPTX_PP_ISSUE_A_ROWS(ahi_ptr(1), NA - 4);
+        DPTX_PP_ISSUE_A(alo_ptr(1));
+      }
+    }
+  } else if (wm == 0) {
     DPTX_PP_ISSUE_W(w_ptr(0));
     if (G0ALL) DPTX_PP_ISSUE_A_ROWS(alo_ptr(0), NA - 4);
     DPTX_PP_ISSUE_A(ahi_ptr(0));
@@ -797,35 +840,55 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
   // that hipcc resolves with copies: 500 spilled registers)
   PpFrags f0, f1;
-  if constexpr (OVL) {
+  if constexpr (OVL || OVL2) {
     if (wm == 0) {
       int h3 = 0;  // buffer of A rows 0..127 of tile kt
       for (int kt = 0; kt < nk; ++kt) {
+        DPTX_STAMP(0);
         if (kt + 1 < nk) {
           DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
-          DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));
+          if (!OVL2) DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));
         }
+        DPTX_STAMP(1);
         const char* sa = alo_ptr(h3);
         const char* sb = w_ptr(kt & 1);
         h3 = h3 == 2 ? 0 : h3 + 1;
         pp_read(f0, sa, sb, wn, lr, lh, 0);
         pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1's W and A rows 128..255 have landed
+        DPTX_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1's W (OVL: and A rows 128..255) have landed
+        DPTX_STAMP(3);
         asm volatile("s_barrier" ::: "memory");
       }
     } else {
-      int h3 = 2;  // buffer of A rows 0..127 of tile kt + 2
+      // the second-dispatched half of a workgroup loses the issue arbitration to the older half whenever both are ready
+      // (slot trace: group 1's 32 MFMAs took 2380 cycles next to group 0's 1390); group 1 multiplies FIRST in this
+      // schedule, so it gets the higher priority and group 0 fills the gaps it leaves
+#ifndef DPTX_OVL_PRIO
+#define DPTX_OVL_PRIO 2
+#endif
+      __builtin_amdgcn_s_setprio(DPTX_OVL_PRIO);
+      int h3 = 2, hr = 0;  // buffers of tile kt + 2 (written) and of tile kt (A rows 128..255, OVL2: read)
       for (int kt = 0; kt < nk; ++kt) {
-        const char* sa = ahi_ptr(kt & 1);
+        DPTX_STAMP(0);
+        const char* sa = ahi_ptr(OVL2 ? hr : kt & 1);
         const char* sb = w_ptr(kt & 1);
+        hr = hr == 2 ? 0 : hr + 1;
         pp_read(f0, sa, sb, wn, lr, lh, 0);
         pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
+        DPTX_STAMP(1);
         const bool more = kt + 2 < nk;
-        if (more) DPTX_PP_ISSUE_A(alo_ptr(h3));
+        if (more) {
+          if (OVL2) DPTX_PP_ISSUE_A_ROWS(ahi_ptr(h3), NA - 4);
+          DPTX_PP_ISSUE_A(alo_ptr(h3));
+        }
         h3 = h3 == 2 ? 0 : h3 + 1;
-        // A rows 0..127 of tile kt+1 (issued an iteration ago) have landed; the four pieces just issued may fly
-        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DPTX_STAMP(2);
+        // A of tile kt+1 (issued an iteration ago) has landed; the pieces just issued (4, OVL2: 8) may fly
+        if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (OVL2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        DPTX_STAMP(3);
         asm volatile("s_barrier" ::: "memory");
       }
     }
@@ -838,10 +901,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       const char* sa = alo_ptr(kt & 1);
       const char* sb = w_ptr(kt & 1);
       if (G0ALL) pp_read(f0, sa, sb, wn, lr, lh, 0);             // tile kt is complete: its first fragments now
-      if (kt + 1 < nk) DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
+      if (kt + 1 < nk) DPTX_PP_LOOP_ISSUE_W(w_ptr((kt + 1) & 1));
       const bool more_a = A3 ? kt + 2 < nk : kt + 1 < nk;
       if (G0ALL && more_a) DPTX_PP_ISSUE_A_ROWS(alo_ptr((kt + 1) & 1), NA - 4);
-      if (more_a) DPTX_PP_ISSUE_A(ahi_ptr(A3 ? h_wr : (kt + 1) & 1));
+      if (more_a) DPTX_PP_LOOP_ISSUE_A(ahi_ptr(A3 ? h_wr : (kt + 1) & 1));
       if (A3) h_wr = h_wr == 2 ? 0 : h_wr + 1;
       DPTX_STAMP(1);
       asm volatile("s_barrier" ::: "memory");
@@ -867,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       DPTX_STAMP(1);                                             // tile) has landed before group 0 reads it in slot 2
       asm volatile("s_barrier" ::: "memory");
       DPTX_STAMP(2);
-      if (!G0ALL && kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
+      if (!G0ALL && kt + 1 < nk) DPTX_PP_LOOP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
       DPTX_STAMP(3);
       asm volatile("s_barrier" ::: "memory");
     }
@@ -877,6 +940,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 #undef DPTX_STAMP
 #undef DPTX_PP_ISSUE_W
+#undef DPTX_PP_LOOP_ISSUE_W
+#undef DPTX_PP_LOOP_ISSUE_A
 #undef DPTX_PP_ISSUE_A
 #undef DPTX_PP_ISSUE_A_ROWS
 #undef DPTX_PP_NEXT
@@ -1033,6 +1098,38 @@ __global__ __launch_bounds__(512, 2) void gemm_halo_kernel(const GemmParams p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifndef DPTX_HALO_TWO_BARRIERS
+  // ONE barrier per tap and overlapping MFMA slots (the schedule of gemm_pp_kernel VAR 3): group 0 issues the W pieces of
+  // the next tap and goes straight into its MFMAs; group 1 multiplies first -- with the higher issue priority, or the older
+  // half of the workgroup starves it -- and then issues its share of the next chunk's halo.
+  if (wm == 0) {
+    for (int cc = 0; cc < nch; ++cc) {
+      const char* hb = h_ptr(cc & 1);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int wb = (cc + tap) & 1;
+        if (tap < 8) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), tap + 1, cc * BK);
+        else if (cc + 1 < nch) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), 0, (cc + 1) * BK);
+        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+      }
+    }
+  } else {
+    __builtin_amdgcn_s_setprio(2);
+    for (int cc = 0; cc < nch; ++cc) {
+      const char* hb = h_ptr(cc & 1);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int wb = (cc + tap) & 1;
+        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);
+        if (2 * tap < HSLOTS && cc + 1 < nch) DPTX_HALO_ISSUE_A(h_ptr((cc + 1) & 1), 2 * tap, (cc + 1) * BK);
+        if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's halo (issued in taps 0..5)
+        asm volatile("s_barrier" ::: "memory");
+      }
+    }
+  }
+#else
   if (wm == 0) {
     for (int cc = 0; cc < nch; ++cc) {
       const char* hb = h_ptr(cc & 1);
@@ -1062,6 +1159,7 @@ __global__ __launch_bounds__(512, 2) void gemm_halo_kernel(const GemmParams p) {
       }
     }
   }
+#endif
 #undef DPTX_HALO_ISSUE_W
 #undef DPTX_HALO_ISSUE_A
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1547,6 +1645,10 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
         } else if (pp == 5) {  // one barrier per k-tile, overlapping MFMA slots
           if (p.a_relu) go(gemm_pp_kernel<DT, true, 3>, smem3);
           else go(gemm_pp_kernel<DT, false, 3>, smem3);
+          done_ = true;
+        } else if (pp == 6) {  // the same, DMA split 8 / 8 (160 KB of LDS)
+          if (p.a_relu) go(gemm_pp_kernel<DT, true, 4>, (size_t)160 * 1024);
+          else go(gemm_pp_kernel<DT, false, 4>, (size_t)160 * 1024);
           done_ = true;
         }
       }

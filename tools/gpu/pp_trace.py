@@ -36,7 +36,12 @@ def report(name, fn):
         b = (s[:, 2] - s[:, 1])[2:-1].mean()
         c = (s[:, 3] - s[:, 2])[2:-1].mean()
         d = (s[1:, 0] - s[:-1, 3])[2:].mean()
-        if w < 4:
+        if os.environ.get("DPTX_PP") == "5":   # single-barrier variant: 0 start | 1 | 2 | 3 before the barrier
+            if w < 4:
+                print(f"  wave {w} (group 0): iteration {it:.0f} = DMA issue {a:.0f} + MFMAs {b:.0f} + vmcnt(0) {c:.0f} + barrier wait {d:.0f}")
+            else:
+                print(f"  wave {w} (group 1): iteration {it:.0f} = MFMAs {a:.0f} + DMA issue {b:.0f} + vmcnt(4) {c:.0f} + barrier wait {d:.0f}")
+        elif w < 4:
             print(f"  wave {w} (group 0): iteration {it:.0f} = DMA issue {a:.0f} + barrier wait {b:.0f} + MFMA slot (reads, 32 MFMAs, vmcnt) {c:.0f} + barrier wait {d:.0f}")
         else:
             print(f"  wave {w} (group 1): iteration {it:.0f} = MFMA slot (reads, 32 MFMAs, vmcnt) {a:.0f} + barrier wait {b:.0f} + DMA issue {c:.0f} + barrier wait {d:.0f}")
