@@ -788,6 +788,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     DPTX_PP_NEXT(kyw, kxw, c0w);                                                                                   \
   } while (0)
 
+// the group that multiplies gets the issue priority over the group that issues DMA (experiment: -DDPTX_PP_PRIO)
+#ifdef DPTX_PP_PRIO
+#define DPTX_PP_MMA_PRIO(X) __builtin_amdgcn_s_setprio(X)
+#else
+#define DPTX_PP_MMA_PRIO(X) do { } while (0)
+#endif
 #if defined(DPTX_PP_PROBE) && DPTX_PP_PROBE == 1   // timing probe (wrong results): no DMA inside the k-loop
 #define DPTX_PP_LOOP_ISSUE_W(DST) do { } while (0)
 #define DPTX_PP_LOOP_ISSUE_A(DST) do { } while (0)
@@ -910,7 +916,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       asm volatile("s_barrier" ::: "memory");
       DPTX_STAMP(2);
       if (!G0ALL) pp_read(f0, sa, sb, wn, lr, lh, 0);            // slot 2
+      DPTX_PP_MMA_PRIO(1);
       pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
+      DPTX_PP_MMA_PRIO(0);
       // what group 1 reads in its next slot has landed: everything (!A3), everything but the newest four pieces (A3)
       if (A3 && more_a) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -925,7 +933,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       const char* sb = w_ptr(kt & 1);
       if (A3) h_rd = h_rd == 2 ? 0 : h_rd + 1;
       pp_read(f0, sa, sb, wn, lr, lh, 0);
+      DPTX_PP_MMA_PRIO(1);
       pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
+      DPTX_PP_MMA_PRIO(0);
       if (!G0ALL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its DMA of the previous slot 2 (A rows 0..127 of THIS
       DPTX_STAMP(1);                                             // tile) has landed before group 0 reads it in slot 2
       asm volatile("s_barrier" ::: "memory");
@@ -940,6 +950,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 #undef DPTX_STAMP
 #undef DPTX_PP_ISSUE_W
+#undef DPTX_PP_MMA_PRIO
 #undef DPTX_PP_LOOP_ISSUE_W
 #undef DPTX_PP_LOOP_ISSUE_A
 #undef DPTX_PP_ISSUE_A
