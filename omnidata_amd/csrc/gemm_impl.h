@@ -962,6 +962,173 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------- 256x128 three-stage kernel (experiment, DPTX_PP=7)
+// The probes of the ping-pong kernel say its DMA side is latency x capacity: ~1800 cycles from issue to landed, one 64-KB
+// k-tile in flight per CU.  Here the tile is 256 x 128 (48 KB per k-tile) and the LDS holds THREE stages (144 KB): two
+// k-tiles = 96 KB are in flight while the third is multiplied.  One barrier per k-tile (schedule of gemm_pp_kernel VAR 3):
+// tile kt is complete when iteration kt starts; group 0 (rows 0..127) issues its half of tile kt+2 and goes into its MFMAs,
+// group 1 (rows 128..255; s_setprio: it is the younger half of the workgroup) multiplies first and issues its half
+// afterwards; every wave waits with vmcnt(6) -- its six pieces of tile kt+2 may fly, tile kt+1's have landed.
+// Waves 4 (M) x 2 (N), wave tile 64 x 64.
+struct P3Frags { u32x4_t a[2], b[2]; };
+template <int DT, bool RELU_A>
+__global__ __launch_bounds__(512, 2) void gemm_p3_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 128, NT = 512, TM = 2, TN = 2, PL = 1;
+  constexpr int A_BYTES = 256 * 128, STAGE = (256 + 128) * 128;  // 48 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves
+  const int g = wave >> 2, q = wave & 3;     // group (128-row half) and wave inside it
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
+    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
+    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
+    if (mt >= tiles_m || l >= tm_per * tn_per) return;
+    m0 = mt * BM;
+    n0 = nt * BN;
+  }
+  // loader: wave q of group g owns rows g*128 + 32 i + 8 q + (lane >> 3) of A (i = 0..3) and g*64 + 32 j + 8 q + (lane >> 3)
+  // of W (j = 0, 1); chunk kc = lane & 7
+  const int kc = lane & 7, r0 = 8 * q + (lane >> 3);
+  const int sc = kc ^ ((r0 >> 1) & 7);
+  int a_iy0[4], a_ix0[4];
+  unsigned a_off[4], w_off[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + g * 128 + r0 + 32 * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    int rem, ox;
+    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
+    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
+    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
+    a_ix0[i] = ox * p.stride - p.pad_l;
+    const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * 8;
+    a_off[i] = (unsigned)(ok ? e * 2 : 0);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) w_off[j] = (unsigned)(((long long)(n0 + g * 64 + r0 + 32 * j) * p.ldw + sc * 8) * 2);
+  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
+
+  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k-tile this wave loads next
+  // this wave's six pieces of the k-tile at (ky, kx, c0) into stage ST; advances the tap
+#define DPTX_P3_ISSUE(ST)                                                                                          \
+  do {                                                                                                             \
+    char* st_ = smem + (ST) * STAGE + q * 1024;                                                                    \
+    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
+    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);                                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(st_ + A_BYTES + (g * 64 + 32 * j) * 128), \
+                                               16, w_off[j] + wk_, 0, 0, 0);                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
+      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(st_ + (g * 128 + 32 * i) * 128), 16, \
+                                               valid ? a_off[i] + tap_ : OOB, 0, 0, 0);                            \
+    }                                                                                                              \
+    if (p.k_tap_fast) {                                                                                            \
+      if (++kx == p.ksz) { kx = 0; if (++ky == p.ksz) { ky = 0; c0 += BK; } }                                      \
+    } else {                                                                                                       \
+      c0 += BK;                                                                                                    \
+      if (c0 >= p.Cin) { c0 = 0; if (++kx == p.ksz) { kx = 0; ++ky; } }                                            \
+    }                                                                                                              \
+  } while (0)
+
+  auto read = [&](P3Frags& f, const char* st, int ks) {
+    const int chunk = 2 * ks + lh;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wm * 64 + i * 32 + lr;
+      f.a[i] = *(const u32x4_t*)(st + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wn * 64 + j * 32 + lr;
+      f.b[j] = *(const u32x4_t*)(st + A_BYTES + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    }
+  };
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto mma = [&](P3Frags& f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (RELU_A) f.a[i] = relu8(f.a[i]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], acc[i][j]);
+    }
+  };
+  P3Frags f0, f1;
+  auto mma_tile3 = [&](const char* st) {
+    read(f0, st, 0);
+    read(f1, st, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    read(f0, st, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    read(f1, st, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1);
+  };
+
+  const int nk = p.K / BK;
+  // prologue: tiles 0 and 1
+  DPTX_P3_ISSUE(0);
+  if (nk > 1) DPTX_P3_ISSUE(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int s_rd = 0, s_wr = 2;
+  if (g == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 2 < nk;
+      if (more) DPTX_P3_ISSUE(s_wr);
+      mma_tile3(smem + s_rd * STAGE);
+      s_rd = s_rd == 2 ? 0 : s_rd + 1;
+      s_wr = s_wr == 2 ? 0 : s_wr + 1;
+      if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+    }
+  } else {
+    __builtin_amdgcn_s_setprio(2);
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 2 < nk;
+      mma_tile3(smem + s_rd * STAGE);
+      if (more) DPTX_P3_ISSUE(s_wr);
+      s_rd = s_rd == 2 ? 0 : s_rd + 1;
+      s_wr = s_wr == 2 ? 0 : s_wr + 1;
+      if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+#undef DPTX_P3_ISSUE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  epilogue<DT, BM, BN, TM, TN, PL, NT, 1>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+#endif
+}
+
 // ------------------------------------------------------------------- halo-resident 3x3 convolution
 // 3x3 / stride 1 / pad 1 convolutions on maps whose width is a multiple of 32 and height a multiple of 8 (the 1/4- and
 // 1/2-resolution maps of the decoder).  The implicit GEMM above fetches every input pixel nine times, once per tap, as part
@@ -1762,6 +1929,27 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
     // GEMM's smaller tiles fill the chip better, and give the same bits)
     if (halo_shape(p) && forced == 0 && (long long)(p.M / p.a_rpi) * (p.Win / 32) * (p.Hin / 8) * (p.N / 256) >= 200)
       return launch_halo<DT>(p, stream);
+  }
+  if constexpr (PL == 1 && DT == DT_BF16) {
+    static int pp7 = -1;  // DPTX_PP=7: the 256x128 three-stage kernel wherever the 256x256 rule would fire (experiment)
+    if (pp7 < 0) { const char* t = getenv("DPTX_PP"); pp7 = (t && atoi(t) == 7) ? 1 : 0; }
+    const bool ok7 = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) &&
+                     (long long)p.N * p.ldw * 2 < (1ll << 31) && p.N % 128 == 0 && p.K >= 512 && p.gn_part == nullptr;
+    if (pp7 && ok7 && m256 * (p.N / 128) >= 200) {
+      const int tiles_m = (int)m256, tiles_n = p.N / 128;
+      GemmParams q = p;
+      choose_xcd_grid(p, tiles_m, tiles_n, q.xcd_m, q.xcd_n);
+      const int tiles = 8 * ((tiles_m + q.xcd_m - 1) / q.xcd_m) * (tiles_n / q.xcd_n);
+      constexpr size_t smem7 = 3 * 48 * 1024;
+      auto go = [&](auto k) {
+        static bool done = false;
+        if (!done) { set_smem_attr(k, smem7); done = true; }
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem7, stream, q);
+      };
+      if (p.a_relu) go(gemm_p3_kernel<DT, true>);
+      else go(gemm_p3_kernel<DT, false>);
+      return hipGetLastError();
+    }
   }
   if constexpr (PL == 1) {
     const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
