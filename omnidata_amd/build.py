@@ -13,6 +13,22 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdptx.so")
 SOURCES = ["gemm.hip", "gemm_fp16.hip", "gemm_x3.hip", "gemm_fp8.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip", "prepost.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_impl.h", os.path.join("..", "..", "include", "dptx.h")]
+EXPERIMENT_HEADERS = [os.path.join("experiments", "gemm_experiments.h"), os.path.join("experiments", "gemm_experiments_dispatch.h")]
+
+
+def source_hash(extra_flags=()) -> str:
+    """sha256 over every source the library is built from (+ the extra compiler flags), 16 hex digits.  build() embeds it
+    in the library (dptx_version() ends in `src=<hash>`) and engine.load_library() compares it with the sources next to
+    the .so it is about to load: a stale binary that travelled with a newer tree is refused instead of silently used."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS + EXPERIMENT_HEADERS):
+        path = os.path.join(CSRC, name)
+        h.update(os.path.basename(name).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(extra_flags).encode())
+    return h.hexdigest()[:16]
 
 
 def _newer(dst: str, srcs) -> bool:
@@ -31,16 +47,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     LIB = os.path.join(HERE, f"libdptx{suffix}.so")
     objdir = os.path.join(CSRC, "build" + suffix)
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS + EXPERIMENT_HEADERS]
+    src_hash = source_hash(extra)
+    hash_file = os.path.join(objdir, "engine.srchash")  # engine.o embeds the hash: rebuilt whenever any source changed
+    old_hash = open(hash_file).read().strip() if os.path.exists(hash_file) else ""
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if not force and _newer(o, [s] + hdrs):
+        if not force and _newer(o, [s] + hdrs) and not (src == "engine.hip" and old_hash != src_hash):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", s, "-o", o]
+        if src == "engine.hip":
+            cmd.insert(-4, f'-DDPTX_SRC_HASH="{src_hash}"')
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -53,6 +74,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(hash_file, "w") as f:
+        f.write(src_hash + "\n")
     return LIB
 
 

@@ -226,18 +226,10 @@ hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, 
   else if (mode == MODE_FP16)
     hipLaunchKernelGGL((attention_kernel<DT_FP16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, 0ll);
   else if (mode == MODE_BF16X3) {
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute((const void*)attention_kernel<DT_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE);
-      done = true;
-    }
+    ensure_dyn_smem((const void*)attention_kernel<DT_BF16, 2>, 4 * ATT_STAGE);
     hipLaunchKernelGGL((attention_kernel<DT_BF16, 2>), grid, dim3(256), 4 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, pl.act);
   } else if (mode == MODE_FP16X3) {
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute((const void*)attention_kernel<DT_FP16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE);
-      done = true;
-    }
+    ensure_dyn_smem((const void*)attention_kernel<DT_FP16, 2>, 4 * ATT_STAGE);
     hipLaunchKernelGGL((attention_kernel<DT_FP16, 2>), grid, dim3(256), 4 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, pl.act);
   } else
     return hipErrorInvalidValue;

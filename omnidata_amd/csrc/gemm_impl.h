@@ -585,10 +585,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
 #endif
 }
 
-// Quarter-step software pipeline of the fragment reads for the 128x64 wave tile (TM = 4, TN = 2) of the 256x256 kernels:
+// Quarter-step software pipeline of the fragment reads for the 128x64 wave tile (TM = 4, TN = 2) of the 256x256 kernel:
 // the six ds_read_b128 of k-step q+1 are in flight under the eight MFMAs of k-step q (two fragment sets = 48 registers,
-// what mma_tile's HK = 2 grouping holds as well), so only the first read of a k-tile is exposed -- and pp_read can issue
-// that one before the barrier in front of the MFMA slot.
+// what mma_tile's HK = 2 grouping holds as well), so only the first read of a k-tile is exposed.
 struct PpFrags { u32x4_t a[4], b[2]; };
 // sa: the wave group's 128-row A tile, sb: the 256-row W tile
 __device__ __forceinline__ void pp_read(PpFrags& f, const char* sa, const char* sb, int wn, int lr, int lh, int ks) {
@@ -617,21 +616,6 @@ __device__ __forceinline__ void pp_mma(PpFrags& f, f32x16_t (&acc)[4][2]) {
 template <int DT, bool RELU_A>
 __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char* sa, const char* sb, int wn, int lr, int lh,
                                             f32x16_t (&acc)[4][2]) {
-#if defined(DPTX_PP_PROBE) && DPTX_PP_PROBE == 2   // timing probe (wrong results): DMA and barriers only
-  return;
-#endif
-#ifdef DPTX_PP_FEWREADS  // timing probe (wrong results): k-steps 1..3 re-use the fragments of k-step 0 -- 6 reads instead of 24
-  f1 = f0;
-  __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, false>(f0, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, false>(f1, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, false>(f0, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, false>(f1, acc);
-  return;
-#endif
   pp_read(f1, sa, sb, wn, lr, lh, 1);
   __builtin_amdgcn_sched_barrier(0);
   pp_mma<DT, RELU_A>(f0, acc);
@@ -648,11 +632,10 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 }
 
 // ------------------------------------------------------------------- ping-pong 256x256 kernel
-// The k-loop trace of gemm_glds_kernel (tools/gpu/gemm_trace.py, profiles/r02_gemm_trace.txt) shows what bounds the
-// 256x256 tile: an iteration is 4100 cycles for 2048 cycles of MFMA work per SIMD, because the eight waves run in
-// lockstep -- they all issue their 8 LDS-DMA instructions first (~100-170 cycles EACH, during which a wave issues nothing
-// else: 850-1400 cycles with the matrix pipe idle), then all read fragments, then the two waves of every SIMD queue their
-// MFMAs behind each other.  The DMA latency itself is hidden (the wait for the next tile is ~300 cycles).
+// The k-loop trace of gemm_glds_kernel (profiles/r02_gemm_trace.txt) shows what bounds a lockstep 256x256 tile: an
+// iteration is 4100 cycles for 2048 cycles of MFMA work per SIMD, because the eight waves all issue their 8 LDS-DMA
+// instructions first (~100-170 cycles EACH, during which a wave issues nothing else), then all read fragments, then the
+// two waves of every SIMD queue their MFMAs behind each other.
 //
 // Here the two wave groups (wm = 0 / 1: the upper / lower 128 rows of the tile, one wave of each on every SIMD) run the
 // SAME work half an iteration apart, two barriers per k-tile:
@@ -663,28 +646,12 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 // group 1 reads -- A rows 128..255 and all of W -- is issued by GROUP 0 one full slot earlier (12 instructions per wave),
 // and group 1 issues only A rows 0..127 (4 instructions), which group 0 reads a full iteration later.  Every wave drains
 // its own DMA (vmcnt(0)) at the end of its MFMA slot, i.e. before the barrier in front of the first reader.
-// A3: three LDS buffers for A rows 128..255 (the pieces group 0 issues and group 1 reads first), 144 KB in all: they are
-// issued TWO tiles ahead, after the W pieces of the next tile, and group 0's wait at the end of its MFMA slot is
-// vmcnt(4) -- the W pieces (L2-resident, quick) must have landed, the four A pieces (streamed from HBM / far L2, the ones
-// the convolutions were seen waiting for) get one more iteration.
-//
-// VAR == 2 (G0ALL): group 0 issues ALL sixteen pieces of the next tile (group 1 none), so that a tile is complete when
-// group 0's vmcnt(0) and the barrier behind its MFMA slot have passed -- which lets group 0 fetch the first fragments of
-// its next MFMA slot BEFORE the barrier in front of that slot (the ~200 cycles of read latency the slot trace shows at
-// the head of every MFMA slot disappear from one of the two).
-//
-// VAR == 3 (OVL): ONE barrier per k-tile and overlapping MFMA slots.  Three LDS buffers for A rows 0..127 (144 KB): group 1
-// multiplies first and then issues its four pieces for tile kt+2, so that everything of tile kt is complete when iteration
-// kt starts -- group 0 issues its twelve pieces for tile kt+1 and goes straight into its own MFMAs of tile kt, without
-// waiting for group 1 to finish; both groups meet at the single barrier at the end of the iteration.
-//
-// VAR == 4 (OVL2): the same with the DMA split 8 / 8: group 0 issues only the W pieces of tile kt+1 (in front of its
-// MFMAs), group 1 -- which idles at the barrier for ~900 cycles in VAR 3 -- issues ALL of A of tile kt+2 behind its MFMAs.
-// Three buffers for both A halves, two for W: 160 KB, the whole LDS.
-template <int DT, bool RELU_A, int VAR>
+// (Round 2 measured seven variants of this schedule -- third LDS buffer, all DMA on one group, one barrier per k-tile with
+// overlapping MFMA slots, s_setprio, the guide's 8-phase structure, a 256x128 three-stage tile, an LDS-resident conv halo
+// -- all <= 0: profiles/r02_experiments.md; the three that are kernels of their own live in experiments/.)
+template <int DT, bool RELU_A>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr bool A3 = VAR == 1, G0ALL = VAR == 2, OVL = VAR == 3, OVL2 = VAR == 4;
   constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
   constexpr int SLABS = TM;
   constexpr int HALF = 128 * 128;  // bytes of a 128-row operand tile
@@ -694,17 +661,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // group = wm
   const int lr = lane & 31, lh = lane >> 5;
-  // LDS map.  !A3: stage b = [A rows 0..127 | A rows 128..255 | W rows 0..255] at b * 64 KB.
-  //            A3: W x 2 at 0, A rows 0..127 x 2 at 64 KB, A rows 128..255 x 3 at 96 KB.
-  //           OVL: W x 2 at 0, A rows 128..255 x 2 at 64 KB, A rows 0..127 x 3 at 96 KB.
-  //          OVL2: W x 2 at 0, A rows 0..127 x 3 at 64 KB, A rows 128..255 x 3 at 112 KB.
-  auto w_ptr = [&](int b) -> char* { return smem + ((A3 || OVL || OVL2) ? b * 2 * HALF : b * 4 * HALF + 2 * HALF); };
-  auto alo_ptr = [&](int b) -> char* {
-    return smem + (OVL2 ? 4 * HALF + b * HALF : OVL ? 6 * HALF + b * HALF : A3 ? 4 * HALF + b * HALF : b * 4 * HALF);
-  };
-  auto ahi_ptr = [&](int h) -> char* {
-    return smem + (OVL2 ? 7 * HALF + h * HALF : OVL ? 4 * HALF + h * HALF : A3 ? 6 * HALF + h * HALF : h * 4 * HALF + HALF);
-  };
+  // LDS map: stage b = [A rows 0..127 | A rows 128..255 | W rows 0..255] at b * 64 KB
+  auto w_ptr = [&](int b) -> char* { return smem + b * 4 * HALF + 2 * HALF; };
+  auto alo_ptr = [&](int b) -> char* { return smem + b * 4 * HALF; };
+  auto ahi_ptr = [&](int b) -> char* { return smem + b * 4 * HALF + HALF; };
 
   const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
   int m0, n0;
@@ -724,13 +684,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   const int kc = t & 7, r0 = t >> 3;
   const int sc = kc ^ ((r0 >> 1) & 7);
   const int a_row0 = wm == 0 ? 128 : 0;
-  // G0ALL: i = 4..7 are A rows 0..127, loaded by group 0 as well; OVL2: i = 4..7 are A rows 128..255, loaded by group 1
-  constexpr int NA = (G0ALL || OVL2) ? 8 : 4;
-  int a_iy0[NA], a_ix0[NA];
-  unsigned a_off[NA];
+  int a_iy0[4], a_ix0[4];
+  unsigned a_off[4];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int m = m0 + (i < 4 ? a_row0 + r0 + 32 * i : (OVL2 ? 128 : 0) + r0 + 32 * (i - 4));
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + a_row0 + r0 + 32 * i;
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
     int rem, ox;
@@ -761,20 +719,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     }                                                                                                              \
   } while (0)
   // this group's four A pieces of the tile at (ky, kx, c0) into the 128-row tile at DST; advances the tap
-#define DPTX_PP_ISSUE_A_ROWS(DST, I0)                                                                              \
+#define DPTX_PP_ISSUE_A(DST)                                                                                       \
   do {                                                                                                             \
     char* d_ = (DST) + wq * 1024;                                                                                  \
     const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
-      const int iy = a_iy0[(I0) + i] + ky, ix = a_ix0[(I0) + i] + kx;                                              \
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
       const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(d_ + 32 * i * 128), 16, \
-                                               valid ? a_off[(I0) + i] + tap_ : OOB, 0, 0, 0);                     \
+                                               valid ? a_off[i] + tap_ : OOB, 0, 0, 0);                            \
     }                                                                                                              \
-  } while (0)
-#define DPTX_PP_ISSUE_A(DST)                                                                                       \
-  do {                                                                                                             \
-    DPTX_PP_ISSUE_A_ROWS(DST, 0);                                                                                  \
     DPTX_PP_NEXT(ky, kx, c0);                                                                                      \
   } while (0)
   // the eight W pieces of the tile at (kyw, kxw, c0w) into the 256-row tile at DST; advances that tap
@@ -788,19 +742,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     DPTX_PP_NEXT(kyw, kxw, c0w);                                                                                   \
   } while (0)
 
-// the group that multiplies gets the issue priority over the group that issues DMA (experiment: -DDPTX_PP_PRIO)
-#ifdef DPTX_PP_PRIO
-#define DPTX_PP_MMA_PRIO(X) __builtin_amdgcn_s_setprio(X)
-#else
-#define DPTX_PP_MMA_PRIO(X) do { } while (0)
-#endif
-#if defined(DPTX_PP_PROBE) && DPTX_PP_PROBE == 1   // timing probe (wrong results): no DMA inside the k-loop
-#define DPTX_PP_LOOP_ISSUE_W(DST) do { } while (0)
-#define DPTX_PP_LOOP_ISSUE_A(DST) do { } while (0)
-#else
-#define DPTX_PP_LOOP_ISSUE_W(DST) DPTX_PP_ISSUE_W(DST)
-#define DPTX_PP_LOOP_ISSUE_A(DST) DPTX_PP_ISSUE_A(DST)
-#endif
   f32x16_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -814,133 +755,54 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   long long* trp = p.trace + wave * 4 * 64;
 #ifdef DPTX_TRACE   // experiment builds only (build.py DPTX_CXXFLAGS=-DDPTX_TRACE): the stamps cost registers and issue slots
 #define DPTX_STAMP(SLOT) do { if (tr && kt < 64) trp[kt * 4 + (SLOT)] = (long long)__builtin_readcyclecounter(); } while (0)
+  if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
 #else
 #define DPTX_STAMP(SLOT) do { } while (0)
+  (void)tr; (void)trp;
 #endif
-#ifdef DPTX_TRACE
-  if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
-#endif
-  // prologue: tile 0 (A3: also A rows 128..255 of tile 1)
-  if (OVL2) {
-    if (wm == 0) {
-      DPTX_PP_ISSUE_W(w_ptr(0));
-    } else {
-      DPTX_PP_ISSUE_A_ROWS(ahi_ptr(0), NA - 4);
-      DPTX_PP_ISSUE_A(alo_ptr(0));
-      if (nk > 1) {
-        DPTX_PP_ISSUE_A_ROWS(ahi_ptr(1), NA - 4);
-        DPTX_PP_ISSUE_A(alo_ptr(1));
-      }
-    }
-  } else if (wm == 0) {
+  // prologue: tile 0
+  if (wm == 0) {
     DPTX_PP_ISSUE_W(w_ptr(0));
-    if (G0ALL) DPTX_PP_ISSUE_A_ROWS(alo_ptr(0), NA - 4);
     DPTX_PP_ISSUE_A(ahi_ptr(0));
-    if (A3 && nk > 1) DPTX_PP_ISSUE_A(ahi_ptr(1));
-  } else if (!G0ALL) {
+  } else {
     DPTX_PP_ISSUE_A(alo_ptr(0));
-    if (OVL && nk > 1) DPTX_PP_ISSUE_A(alo_ptr(1));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
   // that hipcc resolves with copies: 500 spilled registers)
   PpFrags f0, f1;
-  if constexpr (OVL || OVL2) {
-    if (wm == 0) {
-      int h3 = 0;  // buffer of A rows 0..127 of tile kt
-      for (int kt = 0; kt < nk; ++kt) {
-        DPTX_STAMP(0);
-        if (kt + 1 < nk) {
-          DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
-          if (!OVL2) DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));
-        }
-        DPTX_STAMP(1);
-        const char* sa = alo_ptr(h3);
-        const char* sb = w_ptr(kt & 1);
-        h3 = h3 == 2 ? 0 : h3 + 1;
-        pp_read(f0, sa, sb, wn, lr, lh, 0);
-        pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-        DPTX_STAMP(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1's W (OVL: and A rows 128..255) have landed
-        DPTX_STAMP(3);
-        asm volatile("s_barrier" ::: "memory");
-      }
-    } else {
-      // the second-dispatched half of a workgroup loses the issue arbitration to the older half whenever both are ready
-      // (slot trace: group 1's 32 MFMAs took 2380 cycles next to group 0's 1390); group 1 multiplies FIRST in this
-      // schedule, so it gets the higher priority and group 0 fills the gaps it leaves
-#ifndef DPTX_OVL_PRIO
-#define DPTX_OVL_PRIO 2
-#endif
-      __builtin_amdgcn_s_setprio(DPTX_OVL_PRIO);
-      int h3 = 2, hr = 0;  // buffers of tile kt + 2 (written) and of tile kt (A rows 128..255, OVL2: read)
-      for (int kt = 0; kt < nk; ++kt) {
-        DPTX_STAMP(0);
-        const char* sa = ahi_ptr(OVL2 ? hr : kt & 1);
-        const char* sb = w_ptr(kt & 1);
-        hr = hr == 2 ? 0 : hr + 1;
-        pp_read(f0, sa, sb, wn, lr, lh, 0);
-        pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-        DPTX_STAMP(1);
-        const bool more = kt + 2 < nk;
-        if (more) {
-          if (OVL2) DPTX_PP_ISSUE_A_ROWS(ahi_ptr(h3), NA - 4);
-          DPTX_PP_ISSUE_A(alo_ptr(h3));
-        }
-        h3 = h3 == 2 ? 0 : h3 + 1;
-        DPTX_STAMP(2);
-        // A of tile kt+1 (issued an iteration ago) has landed; the pieces just issued (4, OVL2: 8) may fly
-        if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (OVL2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        DPTX_STAMP(3);
-        asm volatile("s_barrier" ::: "memory");
-      }
-    }
-  } else
   if (wm == 0) {
-    int h_wr = 2;  // A3: buffer of A rows 128..255 of tile kt + 2
     for (int kt = 0; kt < nk; ++kt) {
       DPTX_STAMP(0);
-      // slot 1: the DMA.  !A3: W and A rows 128..255 of tile kt+1.  A3: W of tile kt+1, then A rows 128..255 of tile kt+2.
+      // slot 1: the DMA -- W and A rows 128..255 of tile kt+1
       const char* sa = alo_ptr(kt & 1);
       const char* sb = w_ptr(kt & 1);
-      if (G0ALL) pp_read(f0, sa, sb, wn, lr, lh, 0);             // tile kt is complete: its first fragments now
-      if (kt + 1 < nk) DPTX_PP_LOOP_ISSUE_W(w_ptr((kt + 1) & 1));
-      const bool more_a = A3 ? kt + 2 < nk : kt + 1 < nk;
-      if (G0ALL && more_a) DPTX_PP_ISSUE_A_ROWS(alo_ptr((kt + 1) & 1), NA - 4);
-      if (more_a) DPTX_PP_LOOP_ISSUE_A(ahi_ptr(A3 ? h_wr : (kt + 1) & 1));
-      if (A3) h_wr = h_wr == 2 ? 0 : h_wr + 1;
+      if (kt + 1 < nk) {
+        DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
+        DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));
+      }
       DPTX_STAMP(1);
       asm volatile("s_barrier" ::: "memory");
       DPTX_STAMP(2);
-      if (!G0ALL) pp_read(f0, sa, sb, wn, lr, lh, 0);            // slot 2
-      DPTX_PP_MMA_PRIO(1);
+      pp_read(f0, sa, sb, wn, lr, lh, 0);            // slot 2
       pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-      DPTX_PP_MMA_PRIO(0);
-      // what group 1 reads in its next slot has landed: everything (!A3), everything but the newest four pieces (A3)
-      if (A3 && more_a) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what group 1 reads in its next slot has landed
       DPTX_STAMP(3);
       asm volatile("s_barrier" ::: "memory");
     }
   } else {
-    int h_rd = 0;
     for (int kt = 0; kt < nk; ++kt) {
       DPTX_STAMP(0);
-      const char* sa = ahi_ptr(A3 ? h_rd : kt & 1);              // slot 1
+      const char* sa = ahi_ptr(kt & 1);              // slot 1
       const char* sb = w_ptr(kt & 1);
-      if (A3) h_rd = h_rd == 2 ? 0 : h_rd + 1;
       pp_read(f0, sa, sb, wn, lr, lh, 0);
-      DPTX_PP_MMA_PRIO(1);
       pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-      DPTX_PP_MMA_PRIO(0);
-      if (!G0ALL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its DMA of the previous slot 2 (A rows 0..127 of THIS
-      DPTX_STAMP(1);                                             // tile) has landed before group 0 reads it in slot 2
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its DMA of the previous slot 2 (A rows 0..127 of THIS
+      DPTX_STAMP(1);                                    // tile) has landed before group 0 reads it in slot 2
       asm volatile("s_barrier" ::: "memory");
       DPTX_STAMP(2);
-      if (!G0ALL && kt + 1 < nk) DPTX_PP_LOOP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
+      if (kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
       DPTX_STAMP(3);
       asm volatile("s_barrier" ::: "memory");
     }
@@ -950,11 +812,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 #undef DPTX_STAMP
 #undef DPTX_PP_ISSUE_W
-#undef DPTX_PP_MMA_PRIO
-#undef DPTX_PP_LOOP_ISSUE_W
-#undef DPTX_PP_LOOP_ISSUE_A
 #undef DPTX_PP_ISSUE_A
-#undef DPTX_PP_ISSUE_A_ROWS
 #undef DPTX_PP_NEXT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -962,629 +820,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 }
 
-// ------------------------------------------------------------------- 256x128 three-stage kernel (experiment, DPTX_PP=7)
-// The probes of the ping-pong kernel say its DMA side is latency x capacity: ~1800 cycles from issue to landed, one 64-KB
-// k-tile in flight per CU.  Here the tile is 256 x 128 (48 KB per k-tile) and the LDS holds THREE stages (144 KB): two
-// k-tiles = 96 KB are in flight while the third is multiplied.  One barrier per k-tile (schedule of gemm_pp_kernel VAR 3):
-// tile kt is complete when iteration kt starts; group 0 (rows 0..127) issues its half of tile kt+2 and goes into its MFMAs,
-// group 1 (rows 128..255; s_setprio: it is the younger half of the workgroup) multiplies first and issues its half
-// afterwards; every wave waits with vmcnt(6) -- its six pieces of tile kt+2 may fly, tile kt+1's have landed.
-// Waves 4 (M) x 2 (N), wave tile 64 x 64.
-struct P3Frags { u32x4_t a[2], b[2]; };
-template <int DT, bool RELU_A>
-__global__ __launch_bounds__(512, 2) void gemm_p3_kernel(const GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 256, BN = 128, NT = 512, TM = 2, TN = 2, PL = 1;
-  constexpr int A_BYTES = 256 * 128, STAGE = (256 + 128) * 128;  // 48 KB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves
-  const int g = wave >> 2, q = wave & 3;     // group (128-row half) and wave inside it
-  const int lr = lane & 31, lh = lane >> 5;
-
-  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
-  int m0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    m0 = mt * BM;
-    n0 = nt * BN;
-  }
-  // loader: wave q of group g owns rows g*128 + 32 i + 8 q + (lane >> 3) of A (i = 0..3) and g*64 + 32 j + 8 q + (lane >> 3)
-  // of W (j = 0, 1); chunk kc = lane & 7
-  const int kc = lane & 7, r0 = 8 * q + (lane >> 3);
-  const int sc = kc ^ ((r0 >> 1) & 7);
-  int a_iy0[4], a_ix0[4];
-  unsigned a_off[4], w_off[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + g * 128 + r0 + 32 * i;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    int rem, ox;
-    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
-    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
-    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
-    a_ix0[i] = ox * p.stride - p.pad_l;
-    const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * 8;
-    a_off[i] = (unsigned)(ok ? e * 2 : 0);
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) w_off[j] = (unsigned)(((long long)(n0 + g * 64 + r0 + 32 * j) * p.ldw + sc * 8) * 2);
-  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
-
-  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k-tile this wave loads next
-  // this wave's six pieces of the k-tile at (ky, kx, c0) into stage ST; advances the tap
-#define DPTX_P3_ISSUE(ST)                                                                                          \
-  do {                                                                                                             \
-    char* st_ = smem + (ST) * STAGE + q * 1024;                                                                    \
-    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
-    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);                                       \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                  \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(st_ + A_BYTES + (g * 64 + 32 * j) * 128), \
-                                               16, w_off[j] + wk_, 0, 0, 0);                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
-      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
-      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(st_ + (g * 128 + 32 * i) * 128), 16, \
-                                               valid ? a_off[i] + tap_ : OOB, 0, 0, 0);                            \
-    }                                                                                                              \
-    if (p.k_tap_fast) {                                                                                            \
-      if (++kx == p.ksz) { kx = 0; if (++ky == p.ksz) { ky = 0; c0 += BK; } }                                      \
-    } else {                                                                                                       \
-      c0 += BK;                                                                                                    \
-      if (c0 >= p.Cin) { c0 = 0; if (++kx == p.ksz) { kx = 0; ++ky; } }                                            \
-    }                                                                                                              \
-  } while (0)
-
-  auto read = [&](P3Frags& f, const char* st, int ks) {
-    const int chunk = 2 * ks + lh;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = wm * 64 + i * 32 + lr;
-      f.a[i] = *(const u32x4_t*)(st + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = wn * 64 + j * 32 + lr;
-      f.b[j] = *(const u32x4_t*)(st + A_BYTES + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-    }
-  };
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto mma = [&](P3Frags& f) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (RELU_A) f.a[i] = relu8(f.a[i]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], acc[i][j]);
-    }
-  };
-  P3Frags f0, f1;
-  auto mma_tile3 = [&](const char* st) {
-    read(f0, st, 0);
-    read(f1, st, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f0);
-    __builtin_amdgcn_sched_barrier(0);
-    read(f0, st, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f1);
-    __builtin_amdgcn_sched_barrier(0);
-    read(f1, st, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f1);
-  };
-
-  const int nk = p.K / BK;
-  // prologue: tiles 0 and 1
-  DPTX_P3_ISSUE(0);
-  if (nk > 1) DPTX_P3_ISSUE(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int s_rd = 0, s_wr = 2;
-  if (g == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + 2 < nk;
-      if (more) DPTX_P3_ISSUE(s_wr);
-      mma_tile3(smem + s_rd * STAGE);
-      s_rd = s_rd == 2 ? 0 : s_rd + 1;
-      s_wr = s_wr == 2 ? 0 : s_wr + 1;
-      if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-    }
-  } else {
-    __builtin_amdgcn_s_setprio(2);
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + 2 < nk;
-      mma_tile3(smem + s_rd * STAGE);
-      if (more) DPTX_P3_ISSUE(s_wr);
-      s_rd = s_rd == 2 ? 0 : s_rd + 1;
-      s_wr = s_wr == 2 ? 0 : s_wr + 1;
-      if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-    }
-    __builtin_amdgcn_s_setprio(0);
-  }
-#undef DPTX_P3_ISSUE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  epilogue<DT, BM, BN, TM, TN, PL, NT, 1>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+#ifdef DPTX_EXPERIMENTS
+#include "experiments/gemm_experiments.h"
 #endif
-}
 
-// ------------------------------------------------------------------- halo-resident 3x3 convolution
-// 3x3 / stride 1 / pad 1 convolutions on maps whose width is a multiple of 32 and height a multiple of 8 (the 1/4- and
-// 1/2-resolution maps of the decoder).  The implicit GEMM above fetches every input pixel nine times, once per tap, as part
-// of nine different A tiles; here a block owns 8 rows x 32 pixels of ONE image and 256 output channels, keeps the 10 x 34
-// input halo of a 64-channel chunk LDS-resident (43.5 KB) and runs the nine taps out of it: per 64-channel chunk the block
-// moves 43.5 KB of A and 9 x 32 KB of W through the LDS-DMA path instead of 9 x 64 KB (1.7x fewer bytes per flop).
-//
-// k order: chunk-major, taps inside a chunk = GemmParams::k_tap_fast, which launch_gemm forces for every shape this
-// kernel accepts, so that the result is bit-identical to the implicit-GEMM kernels' (small batches fall back to them).
-//
-// Same wave layout and ping-pong schedule as gemm_pp_kernel (group = 4 output rows x 32 pixels x 256 channels); group 0
-// issues the eight W pieces of the next (tap, chunk), group 1 the halo of the NEXT chunk, two of its 43 pieces per wave
-// and tap, which therefore have most of a chunk to land.
-template <int DT, bool RELU_A>
-__global__ __launch_bounds__(512, 2) void gemm_halo_kernel(const GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
-  constexpr int SLABS = TM;
-  constexpr int HC = 34, HPIX = 10 * HC, HPIECES = (HPIX + 7) / 8;  // 340 halo pixels in 43 pieces of 8 rows
-  constexpr int W_BYTES = 256 * 128, HALO_BYTES = 44 * 1024;        // 344 rows x 128 B = 44032 <= 45056
-  constexpr int HSLOTS = (HPIECES + 3) / 4;                         // pieces per wave of group 1: 11
-  extern __shared__ __attribute__((aligned(16))) char smem[];       // W x 2 | halo x 2 = 152 KB
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3, wq = wave & 3;
-  const int lr = lane & 31, lh = lane >> 5;
-  auto w_ptr = [&](int b) -> char* { return smem + b * W_BYTES; };
-  auto h_ptr = [&](int b) -> char* { return smem + 2 * W_BYTES + b * HALO_BYTES; };
-
-  const int tx_n = p.Win >> 5, tpi = tx_n * (p.Hin >> 3);
-  const int tiles_n = p.N / BN, tiles_m = (p.M / p.a_rpi) * tpi;
-  int img, y0, x0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    img = mt / tpi;
-    const int r = mt - img * tpi, ty = r / tx_n;
-    y0 = ty * 8;
-    x0 = (r - ty * tx_n) * 32;
-    n0 = nt * BN;
-  }
-  const int m_base = (img * p.Hin + y0) * p.Win + x0;
-
-  // loader offsets, one array for both roles (the groups never meet in this code):
-  //   group 1, wave wq: halo pieces id = 4 s + wq (s = 0..10); a piece is 8 halo pixels x 128 B, lane (lane>>3, lane&7)
-  //     owns chunk kc of halo pixel hp = 8 id + (lane >> 3); pixels outside the image (and the 4 rows past 339) read zeros
-  //   group 0: W rows r0 + 32 j (j = 0..7) of the 256-row tile, chunk kc (as in gemm_pp_kernel)
-  unsigned offs[HSLOTS];
-  if (wm == 1) {
-    const int kc = lane & 7;
-#pragma unroll
-    for (int s_ = 0; s_ < HSLOTS; ++s_) {
-      const int id = 4 * s_ + wq, hp = 8 * id + (lane >> 3);
-      const int hy = hp / HC, hx = hp - hy * HC;
-      const int y = y0 - 1 + hy, xx = x0 - 1 + hx;
-      const bool ok = id < HPIECES && hp < HPIX && (unsigned)y < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
-      const int sc = kc ^ ((hp >> 1) & 7);
-      const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)y * p.Win + xx) * p.a_pix_stride + sc * 8;
-      offs[s_] = ok ? (unsigned)(e * 2) : OOB;
-    }
-  } else {
-    const int t = tid & 255, kc = t & 7, r0 = t >> 3;
-    const int sc = kc ^ ((r0 >> 1) & 7);
-#pragma unroll
-    for (int j = 0; j < HSLOTS; ++j) offs[j] = j < 8 ? (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2) : 0u;
-  }
-  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
-
-  // halo pieces of slots S0, S0 + 1 (static) of the chunk at channel C0 into halo buffer DST
-#define DPTX_HALO_ISSUE_A(DST, S0, C0)                                                                             \
-  do {                                                                                                             \
-    _Pragma("unroll") for (int s_ = (S0); s_ < (S0) + 2; ++s_) {                                                   \
-      if (s_ < HSLOTS && 4 * s_ + wq < HPIECES)                                                                    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                  \
-            rsrcA, (__attribute__((address_space(3))) void*)((DST) + (4 * s_ + wq) * 1024), 16,                    \
-            offs[s_ < HSLOTS ? s_ : 0] == OOB ? OOB : offs[s_ < HSLOTS ? s_ : 0] + (unsigned)((C0) * 2), 0, 0, 0); \
-    }                                                                                                              \
-  } while (0)
-  // the eight W pieces of (tap TAP, channel chunk C0) into W buffer DST
-#define DPTX_HALO_ISSUE_W(DST, TAP, C0)                                                                            \
-  do {                                                                                                             \
-    char* d_ = (DST) + wq * 1024;                                                                                  \
-    const unsigned wk_ = (unsigned)(((TAP) * p.Cin + (C0)) * 2);                                                   \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(d_ + 32 * j * 128), 16, \
-                                               offs[j] + wk_, 0, 0, 0);                                            \
-  } while (0)
-
-  // fragment reads: A block i = output row 4 wm + i, lane lr = pixel; tap (ky, kx) shifts the halo pixel by ky*34 + kx
-  // (the halo offsets of all nine unrolled taps are loop-invariant; left to itself hipcc hoists the 144 of them out of the
-  // chunk loop and spills -- hp0 is made opaque once per tap so that they are recomputed, ~60 VALU per 32 MFMAs)
-  int hp0 = wm * 4 * HC + lr;
-  auto read = [&](PpFrags& f, const char* hb, const char* sb, int delta, int ks) {
-    const int chunk = 2 * ks + lh;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int hp = hp0 + i * HC + delta;
-      f.a[i] = *(const u32x4_t*)(hb + hp * 128 + ((chunk ^ ((hp >> 1) & 7)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = wn * 64 + j * 32 + lr;
-      f.b[j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-    }
-  };
-  PpFrags f0, f1;
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto mma_tap = [&](const char* hb, const char* sb, int delta) {
-    asm volatile("" : "+v"(hp0));
-    read(f0, hb, sb, delta, 0);
-    read(f1, hb, sb, delta, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    pp_mma<DT, RELU_A>(f0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    read(f0, hb, sb, delta, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    pp_mma<DT, RELU_A>(f1, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    read(f1, hb, sb, delta, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    pp_mma<DT, RELU_A>(f0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    pp_mma<DT, RELU_A>(f1, acc);
-  };
-
-  const int nch = p.Cin / BK;
-  // prologue: the whole halo of chunk 0 (group 1) and W of (tap 0, chunk 0) (group 0)
-  if (wm == 0) {
-    DPTX_HALO_ISSUE_W(w_ptr(0), 0, 0);
-  } else {
-#pragma unroll
-    for (int s0 = 0; s0 < HSLOTS + 1; s0 += 2) DPTX_HALO_ISSUE_A(h_ptr(0), s0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-#ifndef DPTX_HALO_TWO_BARRIERS
-  // ONE barrier per tap and overlapping MFMA slots (the schedule of gemm_pp_kernel VAR 3): group 0 issues the W pieces of
-  // the next tap and goes straight into its MFMAs; group 1 multiplies first -- with the higher issue priority, or the older
-  // half of the workgroup starves it -- and then issues its share of the next chunk's halo.
-  if (wm == 0) {
-    for (int cc = 0; cc < nch; ++cc) {
-      const char* hb = h_ptr(cc & 1);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int wb = (cc + tap) & 1;
-        if (tap < 8) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), tap + 1, cc * BK);
-        else if (cc + 1 < nch) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), 0, (cc + 1) * BK);
-        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-      }
-    }
-  } else {
-    __builtin_amdgcn_s_setprio(2);
-    for (int cc = 0; cc < nch; ++cc) {
-      const char* hb = h_ptr(cc & 1);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int wb = (cc + tap) & 1;
-        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);
-        if (2 * tap < HSLOTS && cc + 1 < nch) DPTX_HALO_ISSUE_A(h_ptr((cc + 1) & 1), 2 * tap, (cc + 1) * BK);
-        if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's halo (issued in taps 0..5)
-        asm volatile("s_barrier" ::: "memory");
-      }
-    }
-  }
-#else
-  if (wm == 0) {
-    for (int cc = 0; cc < nch; ++cc) {
-      const char* hb = h_ptr(cc & 1);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int wb = (cc + tap) & 1;
-        // slot 1: W of the next (tap, chunk)
-        if (tap < 8) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), tap + 1, cc * BK);
-        else if (cc + 1 < nch) DPTX_HALO_ISSUE_W(w_ptr(wb ^ 1), 0, (cc + 1) * BK);
-        asm volatile("s_barrier" ::: "memory");
-        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);        // slot 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-      }
-    }
-  } else {
-    for (int cc = 0; cc < nch; ++cc) {
-      const char* hb = h_ptr(cc & 1);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int wb = (cc + tap) & 1;
-        mma_tap(hb, w_ptr(wb), (tap / 3) * HC + tap % 3);        // slot 1
-        if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's halo (issued in taps 0..5)
-        asm volatile("s_barrier" ::: "memory");
-        if (2 * tap < HSLOTS && cc + 1 < nch) DPTX_HALO_ISSUE_A(h_ptr((cc + 1) & 1), 2 * tap, (cc + 1) * BK);  // slot 2
-        asm volatile("s_barrier" ::: "memory");
-      }
-    }
-  }
-#endif
-#undef DPTX_HALO_ISSUE_W
-#undef DPTX_HALO_ISSUE_A
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m_base, n0, wm, wn, lr, lh, tid, acc, p.Win);
-#endif
-}
-
-// ------------------------------------------------------------------- phased 256x256 kernel
-// Four phases per k-tile, two barriers per phase, the two wave groups (wm = 0 / 1) one barrier apart:
-//
-//     group 0:  | reads + 2 DMA pieces | 8 MFMAs | reads + 2 DMA | 8 MFMAs | ...
-//     group 1:            | 8 MFMAs | reads + 2 DMA pieces | 8 MFMAs | reads + ...
-//
-// so each SIMD always has one wave in its MFMA section while the other fetches its next fragments and issues its share of
-// the LDS-DMA (2 of the 64 one-KB pieces of a k-tile per wave and phase, instead of bursts of 12 / 4 per k-tile in
-// gemm_pp_kernel, whose fragment reads also sat in front of the MFMAs of the SAME wave).
-//
-// A k-tile is four 16-KB half-tiles: H0 = A rows 0..127, H1 = A rows 128..255, H2 = W rows 0..127, H3 = W rows 128..255.
-// Wave (wm, wn) owns rows [64 wm, +64) of H0 AND of H1, columns [32 wn, +32) of H2 AND of H3 (epilogue<ILV>), and its 4 x 2
-// accumulator blocks are visited as (top, j0), (top, j1), (bottom, j1), (bottom, j0): phase 0 reads H0 + H2, phase 1 H3,
-// phase 2 H1, phase 3 H2 again.  Tile t+1 is staged in the same order -- H0, H2, H3, H1 in phases 0..3 of tile t --
-// three (H0: four) phases before it is read, so the DMA of the two most recent steps stays in flight across the
-// barriers: every wave waits at the end of its MFMA section, group 0 with vmcnt(4), group 1 (whose wait comes one barrier
-// later) with vmcnt(2), and vmcnt(0) only in the last k-tile.  A half-tile buffer is re-staged at least two phases after
-// its last fragment read (H2: read in phase 3 of tile t-1, written in phase 1 of tile t).
-template <int DT, bool RELU_A>
-__global__ __launch_bounds__(512, 2) void gemm_ph_kernel(const GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
-  constexpr int SLABS = TM;
-  constexpr int HALF = 128 * 128, TILE_BYTES = 4 * HALF;  // bytes: one half-tile, one k-tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
-  int m0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    m0 = mt * BM;
-    n0 = nt * BN;
-  }
-
-  // loader: a wave-instruction moves 8 rows x 128 B; lane (r8 = lane>>3, kc = lane&7) owns chunk kc of row lrow (and of
-  // row 64 + lrow) of every half-tile.  q = 2*h + z: half h, rows z*64 + lrow.
-  const int kc = lane & 7, lrow = wave * 8 + (lane >> 3);
-  const int sc = kc ^ ((lrow >> 1) & 7);
-  int a_iy0[4], a_ix0[4];
-  unsigned a_off[4], w_off[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int m = m0 + (q >> 1) * 128 + (q & 1) * 64 + lrow;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    int rem, ox;
-    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
-    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
-    a_iy0[q] = ok ? oy * p.stride - p.pad_t : -0x40000000;
-    a_ix0[q] = ox * p.stride - p.pad_l;
-    const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[q] * p.Win + a_ix0[q]) * p.a_pix_stride + sc * 8;
-    a_off[q] = (unsigned)(ok ? e * 2 : 0);
-    w_off[q] = (unsigned)(((long long)(n0 + (q >> 1) * 128 + (q & 1) * 64 + lrow) * p.ldw + sc * 8) * 2);
-  }
-  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
-
-  int ky = 0, kx = 0, c0 = 0;  // tap / channel offset of the k-tile being staged (wave-uniform)
-  const int ld_base = wave * 8 * 128;
-  // the two pieces of A half H (0 / 1) resp. W half H of the k-tile at (ky, kx, c0) into buffer BUF
-#define DPTX_PH_PIECE_A(BUF, H, Z)                                                                                 \
-  do {                                                                                                             \
-    char* d_ = smem + (BUF) * TILE_BYTES + (H) * HALF + ld_base + (Z) * 64 * 128;                                  \
-    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
-    const int iy = a_iy0[2 * (H) + (Z)] + ky, ix = a_ix0[2 * (H) + (Z)] + kx;                                      \
-    const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)d_, 16,               \
-                                             valid ? a_off[2 * (H) + (Z)] + tap_ : OOB, 0, 0, 0);                  \
-  } while (0)
-#define DPTX_PH_PIECE_W(BUF, H, Z)                                                                                 \
-  do {                                                                                                             \
-    char* d_ = smem + (BUF) * TILE_BYTES + (2 + (H)) * HALF + ld_base + (Z) * 64 * 128;                            \
-    const unsigned wk_ = (unsigned)((((ky * p.ksz + kx) * p.Cin) + c0) * 2);                                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)d_, 16,               \
-                                             w_off[2 * (H) + (Z)] + wk_, 0, 0, 0);                                 \
-  } while (0)
-#define DPTX_PH_STAGE_A(BUF, H) do { DPTX_PH_PIECE_A(BUF, H, 0); DPTX_PH_PIECE_A(BUF, H, 1); } while (0)
-#define DPTX_PH_STAGE_W(BUF, H) do { DPTX_PH_PIECE_W(BUF, H, 0); DPTX_PH_PIECE_W(BUF, H, 1); } while (0)
-#define DPTX_PH_NEXT_TAP()                                                                                         \
-  do {                                                                                                             \
-    if (p.k_tap_fast) {                                                                                            \
-      if (++kx == p.ksz) { kx = 0; if (++ky == p.ksz) { ky = 0; c0 += BK; } }                                      \
-    } else {                                                                                                       \
-      c0 += BK;                                                                                                    \
-      if (c0 >= p.Cin) { c0 = 0; if (++kx == p.ksz) { kx = 0; ++ky; } }                                            \
-    }                                                                                                              \
-  } while (0)
-
-  // fragment reads: row r of a half-tile is 128 B, chunk c at ((c ^ ((r >> 1) & 7)) << 4); the swizzle term of all of a
-  // lane's rows is (lr >> 1) & 7 (the wave offsets are multiples of 32 rows)
-  const int sw = (lr >> 1) & 7;
-  const int a_rd = (wm * 64 + lr) * 128, b_rd = (wn * 32 + lr) * 128;
-  int ch[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) ch[ks] = ((2 * ks + lh) ^ sw) << 4;
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / BK;
-  // prologue: all of tile 0
-  DPTX_PH_STAGE_A(0, 0);
-  DPTX_PH_STAGE_W(0, 0);
-  DPTX_PH_STAGE_W(0, 1);
-  DPTX_PH_STAGE_A(0, 1);
-  DPTX_PH_NEXT_TAP();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (wm == 1) asm volatile("s_barrier" ::: "memory");  // group 1 runs one barrier behind
-
-#define DPTX_PH_WAIT()                                                                                             \
-  do {                                                                                                             \
-    if (!stage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
-    else if (wm == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                          \
-  } while (0)
-#define DPTX_PH_MMA(I0, J, BF, HOOK0, HOOK1)                                                                       \
-  do {                                                                                                             \
-    DPTX_PH_PRIO(1);                                                                                               \
-    acc[I0][J] = T16<DT>::mfma32(af[0][0], BF[0], acc[I0][J]);                                                     \
-    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][0], BF[0], acc[I0 + 1][J]);                                             \
-    HOOK0;                                                                                                         \
-    acc[I0][J] = T16<DT>::mfma32(af[0][1], BF[1], acc[I0][J]);                                                     \
-    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][1], BF[1], acc[I0 + 1][J]);                                             \
-    acc[I0][J] = T16<DT>::mfma32(af[0][2], BF[2], acc[I0][J]);                                                     \
-    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][2], BF[2], acc[I0 + 1][J]);                                             \
-    HOOK1;                                                                                                         \
-    acc[I0][J] = T16<DT>::mfma32(af[0][3], BF[3], acc[I0][J]);                                                     \
-    acc[I0 + 1][J] = T16<DT>::mfma32(af[1][3], BF[3], acc[I0 + 1][J]);                                             \
-    DPTX_PH_PRIO(0);                                                                                               \
-  } while (0)
-
-#ifdef DPTX_PH_NOPRIO
-#define DPTX_PH_PRIO(X) do { } while (0)
-#else
-#define DPTX_PH_PRIO(X) __builtin_amdgcn_s_setprio(X)
-#endif
-// DPTX_PH_SPLIT: 0 both DMA pieces of a phase in the load section, 1 one there and one between the MFMAs, 2 both
-// between the MFMAs (the matrix pipe keeps executing while the wave is stuck in the DMA issue)
-#ifndef DPTX_PH_SPLIT
-#define DPTX_PH_SPLIT 0
-#endif
-#define DPTX_PH_L(KIND, BUF, H) do { if (stage) { if (DPTX_PH_SPLIT == 0) DPTX_PH_STAGE_##KIND(BUF, H); else if (DPTX_PH_SPLIT == 1) DPTX_PH_PIECE_##KIND(BUF, H, 0); } } while (0)
-#define DPTX_PH_M0(KIND, BUF, H) do { if (stage && DPTX_PH_SPLIT == 2) DPTX_PH_PIECE_##KIND(BUF, H, 0); } while (0)
-#define DPTX_PH_M1(KIND, BUF, H) do { if (stage && DPTX_PH_SPLIT >= 1) DPTX_PH_PIECE_##KIND(BUF, H, 1); } while (0)
-#ifdef DPTX_PH_STAGE_FIRST   // experiment: DMA pieces in front of the fragment reads
-#define DPTX_PH_LOADS(READS, STAGE) do { STAGE; READS; } while (0)
-#else
-#define DPTX_PH_LOADS(READS, STAGE) do { READS; STAGE; } while (0)
-#endif
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool stage = kt + 1 < nk;
-    const int cb = kt & 1, nb = cb ^ 1;
-    const char* t_ = smem + cb * TILE_BYTES;
-    u32x4_t af[2][4], b0[4], b1[4];
-    // ---- phase 0: (top, j0)
-    DPTX_PH_LOADS(
-        {
-          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const u32x4_t*)(t_ + 2 * HALF + b_rd + ch[ks]);
-          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {
-            af[0][ks] = *(const u32x4_t*)(t_ + a_rd + ch[ks]);
-            af[1][ks] = *(const u32x4_t*)(t_ + a_rd + 32 * 128 + ch[ks]);
-          }
-        },
-        { DPTX_PH_L(A, nb, 0); });
-    asm volatile("s_barrier" ::: "memory");
-    if (RELU_A) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { af[0][ks] = relu8(af[0][ks]); af[1][ks] = relu8(af[1][ks]); }
-    }
-    DPTX_PH_MMA(0, 0, b0, DPTX_PH_M0(A, nb, 0), DPTX_PH_M1(A, nb, 0));
-    DPTX_PH_WAIT();
-    asm volatile("s_barrier" ::: "memory");
-    // ---- phase 1: (top, j1)
-    DPTX_PH_LOADS({ _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b1[ks] = *(const u32x4_t*)(t_ + 3 * HALF + b_rd + ch[ks]); },
-                  { DPTX_PH_L(W, nb, 0); });
-    asm volatile("s_barrier" ::: "memory");
-    DPTX_PH_MMA(0, 1, b1, DPTX_PH_M0(W, nb, 0), DPTX_PH_M1(W, nb, 0));
-    DPTX_PH_WAIT();
-    asm volatile("s_barrier" ::: "memory");
-    // ---- phase 2: (bottom, j1)
-    DPTX_PH_LOADS(
-        {
-          _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {
-            af[0][ks] = *(const u32x4_t*)(t_ + HALF + a_rd + ch[ks]);
-            af[1][ks] = *(const u32x4_t*)(t_ + HALF + a_rd + 32 * 128 + ch[ks]);
-          }
-        },
-        { DPTX_PH_L(W, nb, 1); });
-    asm volatile("s_barrier" ::: "memory");
-    if (RELU_A) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { af[0][ks] = relu8(af[0][ks]); af[1][ks] = relu8(af[1][ks]); }
-    }
-    DPTX_PH_MMA(2, 1, b1, DPTX_PH_M0(W, nb, 1), DPTX_PH_M1(W, nb, 1));
-    DPTX_PH_WAIT();
-    asm volatile("s_barrier" ::: "memory");
-    // ---- phase 3: (bottom, j0)
-    DPTX_PH_LOADS({ _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) b0[ks] = *(const u32x4_t*)(t_ + 2 * HALF + b_rd + ch[ks]); },
-                  { DPTX_PH_L(A, nb, 1); });
-    asm volatile("s_barrier" ::: "memory");
-    DPTX_PH_MMA(2, 0, b0, DPTX_PH_M0(A, nb, 1), DPTX_PH_M1(A, nb, 1));
-    if (stage) DPTX_PH_NEXT_TAP();
-    DPTX_PH_WAIT();
-    asm volatile("s_barrier" ::: "memory");
-  }
-  if (wm == 0) asm volatile("s_barrier" ::: "memory");  // group 0 catches up
-#undef DPTX_PH_MMA
-#undef DPTX_PH_WAIT
-#undef DPTX_PH_LOADS
-#undef DPTX_PH_PRIO
-#undef DPTX_PH_NEXT_TAP
-#undef DPTX_PH_STAGE_W
-#undef DPTX_PH_STAGE_A
-#undef DPTX_PH_PIECE_W
-#undef DPTX_PH_PIECE_A
-#undef DPTX_PH_L
-#undef DPTX_PH_M0
-#undef DPTX_PH_M1
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS, true>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
-#endif
-}
 
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_FP32>
 __global__ __launch_bounds__(256, 2) void gemm_reg_kernel(const GemmParams p) {
@@ -1731,10 +970,10 @@ constexpr size_t gemm_smem_bytes() {
   return stage > ct ? stage : ct;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device) --
+// one process may hold engines on several GPUs (kernels.h ensure_dyn_smem, defined in misc.hip)
 template <typename K>
-static void set_smem_attr(K k, size_t smem) {
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-}
+static void set_smem_attr(K k, size_t smem) { ensure_dyn_smem((const void*)k, smem); }
 
 // A/B experiments: DPTX_GEMM=reg forces the register-staged kernel; DPTX_XCD=0 disables the 2-D XCD
 // partition of the tile grid.
@@ -1775,6 +1014,10 @@ static void choose_xcd_grid(const GemmParams& p, int tiles_m, int tiles_n, int& 
   }
 }
 
+#ifdef DPTX_EXPERIMENTS
+#include "experiments/gemm_experiments_dispatch.h"
+#endif
+
 template <int DT, int PL, int BM, int BN, int WM_, int WN_>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
@@ -1786,75 +1029,37 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
                        p.M < (1 << 23);
   if (PL == 2 && !glds_ok) return hipErrorInvalidValue;  // the 3-pass mode exists only on the direct-to-LDS path
   if constexpr (DT != DT_FP8 && PL == 1 && BM == 256 && BN == 256) {
-    static int pp = -1;  // ping-pong schedule of the two wave groups (gemm_pp_kernel); DPTX_PP=0: the lockstep loop (A/B runs)
-    if (pp < 0) { const char* t = getenv("DPTX_PP"); pp = t ? atoi(t) : 1; }
-    // the schedule experiments (DPTX_PP = 2, 3, 4; profiles/r02_experiments.md) are built for bf16 only: each is ~20 s of
-    // hipcc per instantiation
-    if constexpr (DT == DT_BF16) {
-      if (pp == 2 && glds_ok) {
-        auto go = [&](auto k) {
-          static bool done = false;
-          if (!done) { set_smem_attr(k, smem); done = true; }
-          hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
-        };
-        if (p.a_relu) go(gemm_ph_kernel<DT, true>);
-        else go(gemm_ph_kernel<DT, false>);
-        return hipGetLastError();
-      }
-    }
-    if (pp && glds_ok) {
-      // pp == 3: three LDS buffers for A rows 128..255 (144 KB)
-      auto go = [&](auto k, size_t bytes) {
-        static bool done = false;
-        if (!done) { set_smem_attr(k, bytes); done = true; }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), bytes, stream, q);
+#ifdef DPTX_EXPERIMENTS
+    if (experiment_pp() == 2 && DT == DT_BF16 && glds_ok) return launch_ph<DT>(q, tiles, smem, stream);
+    const bool pp = experiment_pp() != 0;  // DPTX_PP=0: the lockstep loop (A/B runs)
+#else
+    constexpr bool pp = true;
+#endif
+    if (pp && glds_ok) {  // ping-pong schedule of the two wave groups (gemm_pp_kernel)
+      auto go = [&](auto k) {
+        set_smem_attr(k, smem);
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
       };
-      constexpr size_t smem3 = 144 * 1024;
-      bool done_ = false;
-      if constexpr (DT == DT_BF16) {
-        if (pp == 3) {
-          if (p.a_relu) go(gemm_pp_kernel<DT, true, 1>, smem3);
-          else go(gemm_pp_kernel<DT, false, 1>, smem3);
-          done_ = true;
-        } else if (pp == 4) {  // group 0 issues all sixteen pieces and pre-reads its first fragments
-          if (p.a_relu) go(gemm_pp_kernel<DT, true, 2>, smem);
-          else go(gemm_pp_kernel<DT, false, 2>, smem);
-          done_ = true;
-        } else if (pp == 5) {  // one barrier per k-tile, overlapping MFMA slots
-          if (p.a_relu) go(gemm_pp_kernel<DT, true, 3>, smem3);
-          else go(gemm_pp_kernel<DT, false, 3>, smem3);
-          done_ = true;
-        } else if (pp == 6) {  // the same, DMA split 8 / 8 (160 KB of LDS)
-          if (p.a_relu) go(gemm_pp_kernel<DT, true, 4>, (size_t)160 * 1024);
-          else go(gemm_pp_kernel<DT, false, 4>, (size_t)160 * 1024);
-          done_ = true;
-        }
-      }
-      if (!done_) {
-        if (p.a_relu) go(gemm_pp_kernel<DT, true, 0>, smem);
-        else go(gemm_pp_kernel<DT, false, 0>, smem);
-      }
+      if (p.a_relu) go(gemm_pp_kernel<DT, true>);
+      else go(gemm_pp_kernel<DT, false>);
       return hipGetLastError();
     }
   }
   if constexpr (DT == DT_FP8) {  // fp8 operands: direct-to-LDS path only, pre-activation is the producer's job
     if (!glds_ok || p.a_relu) return hipErrorInvalidValue;
     auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
-    static bool done = false;
-    if (!done) { set_smem_attr(k, smem); done = true; }
+    set_smem_attr(k, smem);
     hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     return hipGetLastError();
   } else
   if (glds_ok && (PL == 2 || gemm_variant() != 1)) {
     if (p.a_relu) {
       auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL>;
-      static bool done = false;
-      if (!done) { set_smem_attr(k, smem); done = true; }
+      set_smem_attr(k, smem);
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     } else {
       auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
-      static bool done = false;
-      if (!done) { set_smem_attr(k, smem); done = true; }
+      set_smem_attr(k, smem);
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     }
   } else if constexpr (WM_ * WN_ != 4) {
@@ -1863,48 +1068,14 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr size_t smem1 = gemm_smem_bytes<BM, BN, 1>();
     if (p.a_fp32) {
       auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, true>;
-      static bool done = false;
-      if (!done) { set_smem_attr(k, smem1); done = true; }
+      set_smem_attr(k, smem1);
       hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, q);
     } else {
       auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, false>;
-      static bool done = false;
-      if (!done) { set_smem_attr(k, smem1); done = true; }
+      set_smem_attr(k, smem1);
       hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, q);
     }
   }
-  return hipGetLastError();
-}
-
-// Shapes gemm_halo_kernel accepts: 3x3 / stride 1 / pad 1 on a dense NHWC map whose width is a multiple of 32 and height a
-// multiple of 8, Cin % 64 == 0, N % 256 == 0, 16-bit operands, no GroupNorm statistics.  launch_gemm forces k_tap_fast for
-// them whichever kernel ends up running, so that the k order -- and with it every bit of the result -- is the same.
-static bool halo_shape(const GemmParams& p) {
-  // Measured (profiles/r02_experiments.md): 917 vs 949 TF/s on rcu@96 -- the 1.7x fewer DMA bytes do not pay, the loop is
-  // bound by the ping-pong structure (one group's 32 MFMAs + first-read latency + barrier per slot), not by operand
-  // traffic.  Off unless DPTX_HALO=1.
-  static int on = -1;
-  if (on < 0) { const char* t = getenv("DPTX_HALO"); on = (t && t[0] == '1') ? 1 : 0; }
-  return on && p.ksz == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.Wout == p.Win && p.a_rpi == p.Hin * p.Win &&
-         p.Win % 32 == 0 && p.Hin % 8 == 0 && p.Cin % 64 == 0 && p.N % 256 == 0 && p.K == 9 * p.Cin && !p.a_fp32 &&
-         p.gn_part == nullptr && p.M % p.a_rpi == 0 && p.c_rpi == 0x7fffffff && p.a_bytes > 0 && p.a_bytes < (1ll << 31) &&
-         (long long)p.N * p.ldw * 2 < (1ll << 31);
-}
-
-template <int DT>
-static hipError_t launch_halo(const GemmParams& p, hipStream_t stream) {
-  const int tiles_m = (p.M / p.a_rpi) * (p.Win / 32) * (p.Hin / 8), tiles_n = p.N / 256;
-  GemmParams q = p;
-  choose_xcd_grid(p, tiles_m, tiles_n, q.xcd_m, q.xcd_n);
-  const int tiles = 8 * ((tiles_m + q.xcd_m - 1) / q.xcd_m) * (tiles_n / q.xcd_n);
-  constexpr size_t smem = 2 * 32 * 1024 + 2 * 44 * 1024;
-  auto go = [&](auto k) {
-    static bool done = false;
-    if (!done) { set_smem_attr(k, smem); done = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
-  };
-  if (p.a_relu) go(gemm_halo_kernel<DT, true>);
-  else go(gemm_halo_kernel<DT, false>);
   return hipGetLastError();
 }
 
@@ -1912,65 +1083,38 @@ template <int DT, int PL>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
   const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
-  static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (experiments)
+  static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (tools/gemm_bench.py)
   if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
   {
     if (forced == 128128 && p.N % 128 == 0) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
     if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
     if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
   }
+#ifdef DPTX_EXPERIMENTS
+  {
+    hipError_t r;
+    if (launch_experiment<DT, PL>(p, forced, m256, stream, r)) return r;
+  }
+#endif
   // 256x256 (8 waves, 1 block/CU; 16-bit modes: the ping-pong kernel): half the DMA issues and 3/4 of the LDS reads per MFMA
   // of the 128x128 tile, but no second block to hide prologue/epilogue and a coarser tail.  Chosen when its estimated
   // efficiency wins: fill of the last round of CUs (256 slots) x 1.25 (the measured per-tile advantage at K >= 512 with the
   // pipelined fragment reads, profiles/r02_experiments.md) against the fill of the 128x128 grid (512 slots).  That picks
   // it for the ViT GEMMs, patch-embed and the 3x3 convs at 1/4 resolution and keeps 128x128 for the small maps.
-  if constexpr (PL == 1 && DT != DT_FP8) {
-    // 3x3 convolutions on the large decoder maps: LDS-resident input halo (from 200 tiles up; below that the implicit
-    // GEMM's smaller tiles fill the chip better, and give the same bits)
-    if (halo_shape(p) && forced == 0 && (long long)(p.M / p.a_rpi) * (p.Win / 32) * (p.Hin / 8) * (p.N / 256) >= 200)
-      return launch_halo<DT>(p, stream);
-  }
-  if constexpr (PL == 1 && DT == DT_BF16) {
-    static int pp7 = -1;  // DPTX_PP=7: the 256x128 three-stage kernel wherever the 256x256 rule would fire (experiment)
-    if (pp7 < 0) { const char* t = getenv("DPTX_PP"); pp7 = (t && atoi(t) == 7) ? 1 : 0; }
-    const bool ok7 = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) &&
-                     (long long)p.N * p.ldw * 2 < (1ll << 31) && p.N % 128 == 0 && p.K >= 512 && p.gn_part == nullptr;
-    if (pp7 && ok7 && m256 * (p.N / 128) >= 200) {
-      const int tiles_m = (int)m256, tiles_n = p.N / 128;
-      GemmParams q = p;
-      choose_xcd_grid(p, tiles_m, tiles_n, q.xcd_m, q.xcd_n);
-      const int tiles = 8 * ((tiles_m + q.xcd_m - 1) / q.xcd_m) * (tiles_n / q.xcd_n);
-      constexpr size_t smem7 = 3 * 48 * 1024;
-      auto go = [&](auto k) {
-        static bool done = false;
-        if (!done) { set_smem_attr(k, smem7); done = true; }
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem7, stream, q);
-      };
-      if (p.a_relu) go(gemm_p3_kernel<DT, true>);
-      else go(gemm_p3_kernel<DT, false>);
-      return hipGetLastError();
-    }
-  }
   if constexpr (PL == 1) {
     const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
-    static int min_k = -1;  // DPTX_T256_MINK: shortest K that takes the 256x256 tile (experiments)
-    if (min_k < 0) { const char* t = getenv("DPTX_T256_MINK"); min_k = t ? atoi(t) : 512; }
-    if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= min_k) {
+    if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= 512) {
       const long long t256 = m256 * (p.N / 256), r256 = (t256 + 255) / 256;
       const long long t128 = m128 * (p.N / 128), r128 = (t128 + 511) / 512;
       const double fill256 = (double)t256 / (double)(r256 * 256), fill128 = (double)t128 / (double)(r128 * 512);
-      static double adv = -1.0;  // DPTX_T256_ADV: per-tile advantage of the 256x256 kernel assumed by the rule (experiments)
-      if (adv < 0.0) { const char* t = getenv("DPTX_T256_ADV"); adv = t ? atof(t) : 1.25; }
-      if (t256 >= 200 && fill256 * adv >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
+      if (t256 >= 200 && fill256 * 1.25 >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
     }
   }
   if constexpr (PL == 2) {
     // 3-MFMA modes are one block per CU (two planes of two stages = 128 KB of LDS); eight waves (2 x 4, wave tile
     // 64 x 32) instead of four put two waves on every SIMD, so that one's fragment reads overlap the other's MFMAs:
-    // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md).  DPTX_X3_W8=0: four waves.
-    static int w8 = -1;
-    if (w8 < 0) { const char* t = getenv("DPTX_X3_W8"); w8 = t ? atoi(t) : 1; }
-    if (w8 && p.N % 128 == 0 && m128 * (p.N / 128) >= 200) return launch_cfg<DT, PL, 128, 128, 2, 4>(p, stream);
+    // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md)
+    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200) return launch_cfg<DT, PL, 128, 128, 2, 4>(p, stream);
   }
   // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
   // 128x64 by 2..10 %, whose second round is nearly empty

@@ -243,14 +243,12 @@ hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const floa
   const int grid = ntiles < cus ? ntiles : cus;
   if (mode == MODE_BF16) {
     auto k = head_tail_kernel<DT_BF16>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_SMEM); done = true; }
+    ensure_dyn_smem((const void*)k, HT_SMEM);
     hipLaunchKernelGGL(k, dim3(grid), dim3(HT_THREADS), HT_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, io, B,
                        Hs, Ws, C, relu_out, ntiles);
   } else {
     auto k = head_tail_kernel<DT_FP16>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HT_SMEM); done = true; }
+    ensure_dyn_smem((const void*)k, HT_SMEM);
     hipLaunchKernelGGL(k, dim3(grid), dim3(HT_THREADS), HT_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, io, B,
                        Hs, Ws, C, relu_out, ntiles);
   }

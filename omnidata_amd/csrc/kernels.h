@@ -7,6 +7,10 @@
 
 namespace dptx {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: sets it once per (kernel, current
+// device) -- one process may hold engines on several GPUs (misc.hip)
+void ensure_dyn_smem(const void* kernel, size_t bytes);
+
 // One implicit-GEMM problem: C[M,N] = epilogue( gatherA[M,K] * W[N,K]^T ).
 // A is addressed as an NHWC image batch so that a dense row-major matrix, a strided 1x1
 // convolution and a kxk convolution are the same code path:

@@ -4,7 +4,21 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace dptx {
+
+void ensure_dyn_smem(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.insert({kernel, dev}).second)
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 // ------------------------------------------------------------------ bilinear x2, align_corners
 // blocks.py:335-337 / dpt_depth.py:93: F.interpolate(scale_factor=2, mode="bilinear",

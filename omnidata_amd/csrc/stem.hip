@@ -122,8 +122,7 @@ hipError_t launch_stem_conv(int mode, const void* x, int io, const void* Wt, voi
   const size_t smem = 256 * 68 * 4;  // C tile (69.6 KB) aliases the patch
   DPTX_DISPATCH_MODE(mode, {
     auto k = stem_conv_kernel<DT, PL>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
+    ensure_dyn_smem((const void*)k, smem);
     hipLaunchKernelGGL(k, grid, dim3(256), smem, stream, x, io, (const uint16_t*)Wt, (uint16_t*)y, H, W, pt, plft, pl.act, pl.w);
   });
   return hipGetLastError();

@@ -95,6 +95,15 @@ def load_library() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        # the binary must have been built from the sources it sits next to (the .so travels with the tree; mtimes do not
+        # prove anything on another machine): dptx_version() ends in "src=<sha256 of csrc/* + include/dptx.h>"
+        if not os.environ.get("DPTX_LIB") and not os.environ.get("DPTX_SKIP_HASH_CHECK"):
+            from .build import source_hash
+            built = lib.dptx_version().decode().rsplit("src=", 1)[-1]
+            want = source_hash(os.environ.get("DPTX_CXXFLAGS", "").split())
+            if built != want:
+                raise RuntimeError(f"{LIB_PATH} is stale: built from sources {built}, the tree has {want}. "
+                                   "Run `python -m omnidata_amd.build`.")
         _lib = lib
     return _lib
 

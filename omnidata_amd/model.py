@@ -40,18 +40,19 @@ class DPTDepthModel(BaseModel):
     """Drop-in for ``DPTDepthModel(backbone={'vitb_rn50_384' | 'vitl16_384'}, num_channels={1,3})``
     (DPT-Hybrid, the published omnidata configuration, and DPT-Large, demo.py:81 / dpt_depth.py:41-45).
 
-    Extra keyword arguments (engine side): ``dtype`` in {'bf16','fp16','bf16x3','fp16x3','mixed'} -- MFMA operand /
-    activation storage type.  'bf16' / 'fp16' are single-pass 16-bit arithmetic (fast; they deviate from the fp32
-    reference forward by ~6e-2 / ~7e-3 max-abs on the seeded weights -- NOT within north_star's 1e-3); 'bf16x3' /
-    'fp16x3' keep hi/lo planes and spend 3 MFMAs per product (meet 1e-3); 'mixed' runs the layer groups in
-    ``x3_groups`` ('resnet+reassemble+rn+fusion+head' by default: everything but the ViT blocks) with 3 MFMAs and the
-    rest single-pass fp16 (meets 1e-3 faster; profiles/r02_precision_frontier.md).  ``max_batch`` -- arena size
-    (larger batches are chunked).
+    Extra keyword arguments (engine side): ``dtype`` in {'mixed','fp16x3','bf16x3','fp16','bf16','fp8'} -- MFMA
+    operand / activation storage type.  The DEFAULT is 'mixed', the mode that matches the reference: the layer groups
+    in ``x3_groups`` ('resnet+embed+reassemble+rn+fusion+head' by default: everything but the ViT blocks) keep hi/lo
+    fp16 planes and spend 3 MFMAs per product, the ViT blocks run single-pass fp16 -- within north_star's 1e-3 of the
+    fp32 reference forward (profiles/r02_precision_frontier.md, oracle/precision_layers.py).  'fp16x3' / 'bf16x3' run
+    everything with 3 MFMAs (reference-grade, ~1e-5 / ~1e-4).  'bf16' / 'fp16' are single-pass THROUGHPUT modes: ~2x
+    faster, but ~6e-2 / ~9e-3 max-abs from the reference on the seeded weights -- NOT within 1e-3; 'fp8' additionally
+    runs the decoder convolutions on e4m3 operands.  ``max_batch`` -- arena size (larger batches are chunked).
     """
 
     def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,
                  backbone: str = "vitb_rn50_384", features: int = 256, readout: str = "project",
-                 channels_last: bool = False, use_bn: bool = False, dtype: str = "bf16",
+                 channels_last: bool = False, use_bn: bool = False, dtype: str = "mixed",
                  max_batch: int = 32, init_seed: int = 0, x3_groups=0):
         super().__init__()
         if backbone not in BACKBONES:
@@ -156,7 +157,7 @@ class DPTDualTaskModel(nn.Module):
     forward(x [B,3,H,W]) -> (normal [B,3,H,W], depth [B,H,W]).
     """
 
-    def __init__(self, dtype: str = "bf16", max_batch: int = 32, init_seed: int = 0, non_negative: bool = True,
+    def __init__(self, dtype: str = "mixed", max_batch: int = 32, init_seed: int = 0, non_negative: bool = True,
                  x3_groups=0):
         super().__init__()
         self.engine_dtype = dtype

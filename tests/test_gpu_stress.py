@@ -13,16 +13,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("streams,iters", [(2, 1000), (3, 300)])
-def test_multi_stream_schedule_stress_bit_identical(streams, iters):
+@pytest.mark.parametrize("dtype,streams,iters", [("bf16", 2, 1000), ("bf16", 3, 300), ("mixed", 2, 400)])
+def test_multi_stream_schedule_stress_bit_identical(dtype, streams, iters):
+    """bf16: the benched throughput mode; mixed: the parity mode (two-plane arena, 3-MFMA tiles, the default dtype of the
+    drop-in surface)."""
     sd = random_state_dict(0, 3)
     B = 6
     x = synthetic_input(5, B, "normal").to(DEV)
-    ref_eng = Engine(num_channels=3, max_batch=B, dtype="bf16", device_id=0, streams=1)
+    ref_eng = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, streams=1)
     ref_eng.load_state_dict(sd)
     ref = ref_eng.forward(x).clone()
     ref_eng.close()
-    eng = Engine(num_channels=3, max_batch=B, dtype="bf16", device_id=0, streams=streams)
+    eng = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, streams=streams)
     eng.load_state_dict(sd)
     out = torch.empty_like(ref)
     # every forward is checked on the device without stalling the streams (the comparison kernels queue up behind the
