@@ -89,8 +89,14 @@ typedef struct dptx_config {
                          /*   (everything except the ViT blocks).  Ignored by the other dtypes.                      */
   int32_t backbone;      /* DPTX_BACKBONE_*: 0 = vitb_rn50_384 (DPT-Hybrid, the default), 1 = vitl16_384 (DPT-Large:  */
                          /*   dpt_depth.py:41-45 hooks [5,11,17,23], blocks.py:12-18, vit.py:176-309; demo.py:81)       */
-  int32_t reserved[2];   /* must be zero                                                        */
+  int32_t flags;         /* OR of DPTX_FLAG_*: switches for A/B runs of the fused schedules (0 = everything on)  */
+  int32_t reserved;      /* must be zero                                                        */
 } dptx_config;
+/* dptx_config.flags.  NO_LN_FOLD: keep the 24 LayerNorm launches of the ViT blocks instead of folding the LayerNorm into
+ * the qkv / fc1 GEMMs (gamma into W, W beta into the bias, (x W' - mu colsum(W')) rstd in the epilogue; row statistics and
+ * the 16-bit operand copy of the fp32 token stream come out of the preceding proj / fc2 / patch-embed epilogue).  The fold
+ * applies to single-pass ViT blocks only (bf16, fp16, fp8, and mixed policies without DPTX_GROUP_VIT). */
+enum { DPTX_FLAG_NO_LN_FOLD = 1 };
 
 /* Fills *cfg with the reference defaults: C=3, max_batch=32, bf16, device 0, non_negative=1,
  * ws_form=0, ws_eps=1e-8. */

@@ -30,8 +30,15 @@ __device__ __forceinline__ int vt_pos(int key) {  // swap bits 2 and 3
   return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
 }
 
-// PL == 2 (bf16x3 mode): q/k/v/p are hi+lo bf16 plane pairs and every product is 3 MFMAs
+// PL == 2 (bf16x3 / fp16x3 modes): q/k/v/p are hi+lo plane pairs and every product is 3 MFMAs
 // (lo*hi + hi*lo + hi*hi); `plane` is the element distance between the planes of qkv / out.
+//
+// Round 3 (profiles/r02_pmc_sq.txt: MFMA busy 10 % of the wave cycles, 34 % issue stalls behind dependent MFMAs, 29 %
+// waits): (a) key 0 -- the cls token -- is handled once per block on the VALU (one 64-long dot product per query, the
+// online-softmax state starts at m = s0, l = 1, O = v0), so the key tiles cover keys 1..S-1: 576 = 9 x 64 of them at
+// 384x384 instead of ten tiles the last of which held ONE key; (b) the two 32-key halves of a tile go through QK^T
+// together (two independent MFMA chains instead of one dependent chain of four) and share ONE running-max update, one
+// alpha and at most one rescale of O per tile; (c) waves whose 32 queries all lie beyond S only stage K / V.
 template <int DT, int PL>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                            int S, int H, int BH, long long plane) {
@@ -52,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   // Q fragments (B operand: lane = query column, 8 consecutive d per k-step)
   const int q = qblk * 128 + wave * 32 + lr;
   const int qc = q < S ? q : S - 1;
+  const bool wave_active = qblk * 128 + wave * 32 < S;  // wave-uniform
   uint4 qf[4], ql[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   }
 
   // staging: thread t loads 16 B (d chunk t&7) of K for keys (t>>3), (t>>3)+32 and of V for the
-  // adjacent key pair 2*(t>>3), 2*(t>>3)+1 (adjacent keys stay adjacent under vt_pos)
+  // adjacent key pair 2*(t>>3), 2*(t>>3)+1 (adjacent keys stay adjacent under vt_pos).  Tile T holds keys 1 + 64 T ...
   const int kc = tid & 7, kr = tid >> 3;
   u32x4_t rk[2 * PL], rv[2 * PL];  // [plane][i]
   const u32x4_t zero4 = {0u, 0u, 0u, 0u};
@@ -68,8 +76,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   do {                                                                                        \
     _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) {                                       \
       _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
-        const int key = (T) * ATT_KT + kr + 32 * i;                                           \
-        const int vkey = (T) * ATT_KT + 2 * kr + i;                                           \
+        const int key = 1 + (T) * ATT_KT + kr + 32 * i;                                       \
+        const int vkey = 1 + (T) * ATT_KT + 2 * kr + i;                                       \
         u32x4_t k4 = zero4, v4 = zero4;                                                       \
         if (key < S) k4 = *(const u32x4_t*)(kbase + pl * plane + (row0 + key) * ld + kc * 8); \
         if (vkey < S) v4 = *(const u32x4_t*)(vbase + pl * plane + (row0 + vkey) * ld + kc * 8); \
@@ -99,93 +107,141 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     }                                                                                         \
   } while (0)
 
-  f32x16_t o[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-  float m_run = -1e30f, l_run = 0.f;
-  const float cexp = 0.125f * 1.4426950408889634f;  // softmax scale folded into exp2
+  const int ntiles = (S - 1 + ATT_KT - 1) / ATT_KT;  // tiles over keys 1 .. S-1
+  if (ntiles > 0) ATT_LOAD_KV(0);
 
-  const int ntiles = (S + ATT_KT - 1) / ATT_KT;
-  ATT_LOAD_KV(0);
-  ATT_STORE_KV(0);
+  const float cexp = 0.125f * 1.4426950408889634f;  // softmax scale folded into exp2
+  // ---- key 0 on the VALU: s0 = <q, k0> (this lane holds 32 of the 64 d of its query; the other 32 sit in lane ^ 32)
+  f32x16_t o[2];
+  float m_run, l_run;
+  {
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float qv[8], kv[8];
+      u32x4_t qh = {qf[ks].x, qf[ks].y, qf[ks].z, qf[ks].w}, qlo = zero4;
+      if (PL == 2) qlo = u32x4_t{ql[ks].x, ql[ks].y, ql[ks].z, ql[ks].w};
+      unpack8x<DT, PL>(qh, qlo, qv);
+      const u32x4_t kh = *(const u32x4_t*)(kbase + row0 * ld + ks * 16 + lh * 8);
+      u32x4_t klo = zero4;
+      if (PL == 2) klo = *(const u32x4_t*)(kbase + plane + row0 * ld + ks * 16 + lh * 8);
+      unpack8x<DT, PL>(kh, klo, kv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part = fmaf(qv[e], kv[e], part);
+    }
+    m_run = part + __shfl_xor(part, 32, 64);
+    l_run = lh == 0 ? 1.f : 0.f;  // p0 = exp2(0) = 1, counted once (the two halves' partial sums are added at the end)
+    // O^T[d][q] = p0 * v0[d]: this lane's rows d = dt*32 + 8g + 4 lh + (0..3)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * lh;
+        const uint2 vh = *(const uint2*)(vbase + row0 * ld + d);
+        float v4[4] = {T16<DT>::tof((uint16_t)(vh.x & 0xffffu)), T16<DT>::tof((uint16_t)(vh.x >> 16)),
+                       T16<DT>::tof((uint16_t)(vh.y & 0xffffu)), T16<DT>::tof((uint16_t)(vh.y >> 16))};
+        if (PL == 2) {
+          const uint2 vl = *(const uint2*)(vbase + plane + row0 * ld + d);
+          v4[0] += T16<DT>::tof((uint16_t)(vl.x & 0xffffu)); v4[1] += T16<DT>::tof((uint16_t)(vl.x >> 16));
+          v4[2] += T16<DT>::tof((uint16_t)(vl.y & 0xffffu)); v4[3] += T16<DT>::tof((uint16_t)(vl.y >> 16));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[dt][4 * g + e] = v4[e];
+      }
+  }
+
+  if (ntiles > 0) ATT_STORE_KV(0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1) < ntiles;
     if (more) ATT_LOAD_KV(t + 1);
     const char* sk = smem + (t & 1) * STAGE;
     const char* sv = sk + ATT_K_BYTES;
+    if (wave_active) {
+      // ---- S^T = K Q^T for both 32-key halves: two independent accumulators
+      f32x16_t s0, s1;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      f32x16_t s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int row = sub * 32 + lr;
         const int chunk = 2 * ks + lh;
-        const int koff = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-        const uint4 kf = *(const uint4*)(sk + koff);
+        const int koff0 = lr * 128 + ((chunk ^ ((lr >> 1) & 7)) << 4);  // rows lr and 32 + lr share (row >> 1) & 7
+        const int koff1 = koff0 + 32 * 128;
+        const uint4 kf0 = *(const uint4*)(sk + koff0);
+        const uint4 kf1 = *(const uint4*)(sk + koff1);
         if (PL == 2) {
-          const uint4 kl = *(const uint4*)(sk + ATT_STAGE + koff);
-          s = T16<DT>::mfma32(kl, qf[ks], s);
-          s = T16<DT>::mfma32(kf, ql[ks], s);
+          const uint4 kl0 = *(const uint4*)(sk + ATT_STAGE + koff0);
+          const uint4 kl1 = *(const uint4*)(sk + ATT_STAGE + koff1);
+          s0 = T16<DT>::mfma32(kl0, qf[ks], s0);
+          s1 = T16<DT>::mfma32(kl1, qf[ks], s1);
+          s0 = T16<DT>::mfma32(kf0, ql[ks], s0);
+          s1 = T16<DT>::mfma32(kf1, ql[ks], s1);
         }
-        s = T16<DT>::mfma32(kf, qf[ks], s);
+        s0 = T16<DT>::mfma32(kf0, qf[ks], s0);
+        s1 = T16<DT>::mfma32(kf1, qf[ks], s1);
       }
-      // s[r] = <K[key], Q[q]> with key = t*64 + sub*32 + (r&3) + 8*(r>>2) + 4*lh, q = this lane's column
-      const int key0 = t * ATT_KT + sub * 32 + 4 * lh;
-      if (key0 + 28 + 3 >= S) {
+      // s0[r] / s1[r] = <K[key], Q[q]> with key = 1 + t*64 + {0, 32} + (r&3) + 8*(r>>2) + 4*lh, q = this lane's column
+      const int key0 = 1 + t * ATT_KT + 4 * lh;
+      if (key0 + 32 + 28 + 3 >= S) {  // only the last tile can hold keys >= S
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (key0 + (r & 3) + 8 * (r >> 2) >= S) s[r] = -1e30f;
+        for (int r = 0; r < 16; ++r) {
+          if (key0 + (r & 3) + 8 * (r >> 2) >= S) s0[r] = -1e30f;
+          if (key0 + 32 + (r & 3) + 8 * (r >> 2) >= S) s1[r] = -1e30f;
+        }
       }
-      float mx = s[0];
+      float mx = s0[0], mx1 = s1[0];  // two chains (hipcc folds each into v_max3_f32)
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      for (int r = 1; r < 16; ++r) { mx = fmaxf(mx, s0[r]); mx1 = fmaxf(mx1, s1[r]); }
+      mx = fmaxf(mx, mx1);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cexp);  // raw v_exp_f32: args are <= 0
       const bool grew = m_new > m_run;
       m_run = m_new;
       const float mc = m_new * cexp;
-      float pv[16];
+      float pv0[16], pv1[16];
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], cexp, -mc));
-        ps += pv[r];
+        pv0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], cexp, -mc));
+        pv1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], cexp, -mc));
+        ps += pv0[r] + pv1[r];
       }
       l_run = l_run * alpha + ps;  // per-half partial sum; halves are added at the end
       if (__any(grew)) {           // wave-uniform: once the running max has settled the rescale is skipped
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
       }
-      uint4 pf[2], pl2[2];
-      pf[0] = pack8<DT>(pv);
-      pf[1] = pack8<DT>(pv + 8);
+      uint4 pf[4], pl2[4];  // [sub * 2 + s2]
+      pf[0] = pack8<DT>(pv0);
+      pf[1] = pack8<DT>(pv0 + 8);
+      pf[2] = pack8<DT>(pv1);
+      pf[3] = pack8<DT>(pv1 + 8);
       if (PL == 2) {
-        float ph[16];
-        unpack8<DT>(pf[0], ph);
-        unpack8<DT>(pf[1], ph + 8);
+        float ph[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ph[r] = pv[r] - ph[r];
-        pl2[0] = pack8<DT>(ph);
-        pl2[1] = pack8<DT>(ph + 8);
+        for (int i = 0; i < 4; ++i) {
+          const float* src = (i < 2 ? pv0 : pv1) + (i & 1) * 8;
+          unpack8<DT>(pf[i], ph);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) ph[r] = src[r] - ph[r];
+          pl2[i] = pack8<DT>(ph);
+        }
       }
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
+      for (int i = 0; i < 4; ++i) {  // i = sub * 2 + s2: the V^T chunk pair (2 i, 2 i + 1) holds these 16 keys
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int drow = dt * 32 + lr;
-          const int vchunk = sub * 4 + s2 * 2 + lh;
+          const int vchunk = i * 2 + lh;
           const int voff = drow * 128 + ((vchunk ^ ((drow >> 1) & 7) ^ ((drow >> 4) & 3)) << 4);
           const uint4 vf = *(const uint4*)(sv + voff);
           if (PL == 2) {
             const uint4 vl = *(const uint4*)(sv + ATT_STAGE + voff);
-            o[dt] = T16<DT>::mfma32(vl, pf[s2], o[dt]);
-            o[dt] = T16<DT>::mfma32(vf, pl2[s2], o[dt]);
+            o[dt] = T16<DT>::mfma32(vl, pf[i], o[dt]);
+            o[dt] = T16<DT>::mfma32(vf, pl2[i], o[dt]);
           }
-          o[dt] = T16<DT>::mfma32(vf, pf[s2], o[dt]);
+          o[dt] = T16<DT>::mfma32(vf, pf[i], o[dt]);
         }
       }
     }

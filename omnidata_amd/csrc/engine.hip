@@ -108,7 +108,9 @@ inline uint8_t f32_to_e4m3(float f) {
 // --------------------------------------------------------------------------- weight spec
 // R_DECONV: ConvTranspose2d [Cin, Cout, k, k] with kernel == stride, packed as the GEMM operand [(dy*k+dx)*Cout + co][ci];
 // R_DECONV_BIAS: its bias, tiled k*k times so that the GEMM epilogue can add it per column
-enum Role { R_STDCONV, R_CONV, R_LINEAR, R_VEC, R_HEAD4, R_UNUSED, R_DECONV, R_DECONV_BIAS };
+// R_DERIVED: fp32 vector that is not part of the state_dict but computed at pack time (LayerNorm fold: column sums of the
+// folded qkv / fc1 weights)
+enum Role { R_STDCONV, R_CONV, R_LINEAR, R_VEC, R_HEAD4, R_UNUSED, R_DECONV, R_DECONV_BIAS, R_DERIVED };
 struct Spec {
   std::string key;
   std::vector<int64_t> shape;
@@ -145,6 +147,8 @@ std::vector<Spec> build_spec(int C, bool dual, int backbone) {
       add(v, p + "mlp.fc1.bias", {D_MLP}, R_VEC);
       add(v, p + "mlp.fc2.weight", {D_VIT, D_MLP}, R_LINEAR);
       add(v, p + "mlp.fc2.bias", {D_VIT}, R_VEC);
+      add(v, p + "attn.qkv.lnsum", {3 * D_VIT}, R_DERIVED);
+      add(v, p + "mlp.fc1.lnsum", {D_MLP}, R_DERIVED);
     }
     add(v, vp + "norm.weight", {D_VIT}, R_UNUSED);
     add(v, vp + "norm.bias", {D_VIT}, R_UNUSED);
@@ -207,6 +211,8 @@ std::vector<Spec> build_spec(int C, bool dual, int backbone) {
     add(v, p + "mlp.fc1.bias", {D_MLP}, R_VEC);
     add(v, p + "mlp.fc2.weight", {D_VIT, D_MLP}, R_LINEAR);
     add(v, p + "mlp.fc2.bias", {D_VIT}, R_VEC);
+    add(v, p + "attn.qkv.lnsum", {3 * D_VIT}, R_DERIVED);
+    add(v, p + "mlp.fc1.lnsum", {D_MLP}, R_DERIVED);
   }
   add(v, vp + "norm.weight", {D_VIT}, R_UNUSED);
   add(v, vp + "norm.bias", {D_VIT}, R_UNUSED);
@@ -269,6 +275,7 @@ size_t packed_entry_bytes(const Spec& s) {
     case R_DECONV:
     case R_LINEAR: return numel(s.shape) * 2;
     case R_VEC:
+    case R_DERIVED:
     case R_HEAD4: return numel(s.shape) * 4;
     case R_DECONV_BIAS: return numel(s.shape) * 4 * 16;  // room for the 4x4 case (the 2x2 one uses a quarter)
     default: return 0;
@@ -316,6 +323,9 @@ struct dptx_engine {
     return (cfg.x3_groups & group) ? MODE_FP16X3 : MODE_FP16;
   }
   bool fp8() const { return cfg.dtype == DPTX_DTYPE_FP8; }
+  // LayerNorm of the ViT blocks folded into the qkv / fc1 GEMMs (include/dptx.h DPTX_FLAG_NO_LN_FOLD): the packed qkv / fc1
+  // weights and biases are then the folded ones, so this is fixed at dptx_create
+  bool ln_fold = false;
   // fp8: the second plane of the arena / blob holds the e4m3 copies (byte offset off / 2 inside it) instead of lo planes
   bool two_planes() const {
     return cfg.dtype == DPTX_DTYPE_BF16X3 || cfg.dtype == DPTX_DTYPE_FP16X3 || cfg.dtype == DPTX_DTYPE_MIXED || fp8();
@@ -363,7 +373,7 @@ struct dptx_engine {
   int max_h = 384, max_w = 384;   // largest supported input (cfg.max_height/max_width; 0 = 384)
   Buf pos_alt;
   Buf sraw, stem, S[3], T1, T2, PA, PB, DS, part[4], X, Hn, QKV, AO, F1, R3, R4, L3, T4, L4, clsb, lrn[4], tA, tB,
-      tC, P[4], H0, H0U, H1;
+      tC, P[4], H0, H0U, H1, lnst;
 
   int fail(int code, const std::string& m) {
     err = m;
@@ -422,6 +432,7 @@ size_t plan_arena_for(dptx_engine* e, size_t B, bool half) {
   // GroupNorm partial records (32 groups x float2): p2/256 chunks for the stem, p4/32 MFMA row blocks for a stage conv
   for (int i = 0; i < 4; ++i) take(e->part[i], B * (std::max(p2 / 256, p4 / 32) + 64) * 64, 4);
   take(e->X, B * S * DV, 4);
+  take(e->lnst, B * S * 8 * 2, 4);  // LayerNorm fold: (sum, sum of squares) per token row and 128-column block (<= 8 blocks)
   take(e->Hn, B * S * DV, 2);
   take(e->QKV, B * S * 3 * DV, 2);
   take(e->AO, B * S * DV, 2);
@@ -462,7 +473,7 @@ void plan_arena(dptx_engine* e) {
 int pack_host(dptx_engine* e) {
   std::string missing;
   for (const auto& s : e->spec)
-    if (s.role != R_UNUSED && !e->staged.count(s.key)) missing += (missing.empty() ? "" : ", ") + s.key;
+    if (s.role != R_UNUSED && s.role != R_DERIVED && !e->staged.count(s.key)) missing += (missing.empty() ? "" : ", ") + s.key;
   if (!missing.empty()) return e->fail(DPTX_E_KEY, "missing tensors (strict load): " + missing);
   e->host_blob.assign(e->packed_bytes, 0);
   const bool bf = e->bf16_storage();
@@ -482,10 +493,50 @@ int pack_host(dptx_engine* e) {
     d16[i] = hi;
     if (x3) d16[i + lo_elems] = f32_to_bf16(x - bf16_to_f32(hi));
   };
+  // value the MFMA sees for a packed single-plane operand element
+  auto r16 = [&](float x) { return bf ? bf16_to_f32(f32_to_bf16(x)) : fp16_to_f32(f32_to_fp16(x)); };
+  auto ends_with = [](const std::string& k, const char* suf) {
+    const size_t n = strlen(suf);
+    return k.size() >= n && k.compare(k.size() - n, n, suf) == 0;
+  };
   for (const auto& s : e->spec) {
-    if (s.role == R_UNUSED) continue;
+    if (s.role == R_UNUSED || s.role == R_DERIVED) continue;
     const std::vector<float>& src = e->staged.at(s.key);
     uint8_t* dst = e->host_blob.data() + e->packed_off.at(s.key);
+    // LayerNorm fold (kernels.h GemmParams::ln_stats): qkv / fc1 of every block become W' = W diag(gamma), b' = b + W beta
+    // and the column sums of the ROUNDED W' go to the derived "...lnsum" entry
+    const bool fold_w = e->ln_fold && s.role == R_LINEAR && (ends_with(s.key, "attn.qkv.weight") || ends_with(s.key, "mlp.fc1.weight"));
+    const bool fold_b = e->ln_fold && s.role == R_VEC && (ends_with(s.key, "attn.qkv.bias") || ends_with(s.key, "mlp.fc1.bias"));
+    if (fold_w || fold_b) {
+      const bool qkv = s.key.find("attn.qkv") != std::string::npos;
+      const std::string blk = s.key.substr(0, s.key.find(qkv ? "attn.qkv" : "mlp.fc1"));
+      const std::string wkey = blk + (qkv ? "attn.qkv.weight" : "mlp.fc1.weight");
+      const std::vector<float>& W = e->staged.at(wkey);
+      const std::vector<float>& gamma = e->staged.at(blk + (qkv ? "norm1.weight" : "norm2.weight"));
+      const std::vector<float>& beta = e->staged.at(blk + (qkv ? "norm1.bias" : "norm2.bias"));
+      const size_t K = gamma.size(), N = W.size() / K;
+      if (fold_b) {
+        float* d32 = (float*)dst;
+        for (size_t n = 0; n < N; ++n) {
+          double acc = src[n];
+          for (size_t k = 0; k < K; ++k) acc += (double)W[n * K + k] * (double)beta[k];
+          d32[n] = (float)acc;
+        }
+      } else {
+        uint16_t* d16 = (uint16_t*)dst;
+        float* cs = (float*)(e->host_blob.data() + e->packed_off.at(blk + (qkv ? "attn.qkv.lnsum" : "mlp.fc1.lnsum")));
+        for (size_t n = 0; n < N; ++n) {
+          double acc = 0.0;
+          for (size_t k = 0; k < K; ++k) {
+            const float wf = W[n * K + k] * gamma[k];
+            put(d16, n * K + k, wf);
+            acc += (double)r16(wf);
+          }
+          cs[n] = (float)acc;
+        }
+      }
+      continue;
+    }
     if (s.role == R_VEC || s.role == R_HEAD4) {
       memcpy(dst, src.data(), src.size() * 4);
       continue;
@@ -747,23 +798,31 @@ int Run::forward(const void* x, void* y, void* y2) {
 
   // ---- tokens: 1x1 proj + bias + pos_embed -> fp32 stream X[b*S + 1 + p] (S = 577 at 384x384); cls rows ----
   float* X = (float*)A(E->X);
+  // LayerNorm fold (kernels.h GemmParams::ln_stats): every launch that writes the fp32 token stream also writes its 16-bit
+  // copy into Hn and the per-row (sum, sum of squares) records into lnst; qkv / fc1 read Hn and normalise in the epilogue
+  float* lnst = (float*)A(E->lnst);
+  const int ln_nblk = D_VIT / 128;
   group(DPTX_GROUP_EMBED);
   {
     // hybrid: the 1x1 projection of the ResNet's 1/16-resolution map (K = 1024); DPT-Large: timm PatchEmbed, a 16x16
     // stride-16 convolution = a dense GEMM over the patch matrix (K = 3*16*16 = 768, misc.hip patchify16)
     const int Kp = large ? 768 : 1024;
-    if (large) chk(launch_patchify16(dt, x, io, A(E->Hn), B, Hi, Wi, E->pl, st), "patchify");
+    // (the patch matrix lives in F1, which is free here: Hn receives the 16-bit copy of the token stream below)
+    if (large) chk(launch_patchify16(dt, x, io, A(E->F1), B, Hi, Wi, E->pl, st), "patchify");
     GemmParams p;
     gemm_params_dense(p, B * NP, D_VIT, Kp);
-    p.A = large ? A(E->Hn) : A(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
+    p.A = large ? A(E->F1) : A(E->S[2]); p.W = E->w(vp + "patch_embed.proj.weight"); p.C = X;
     p.bias = E->f(vp + "patch_embed.proj.bias");
     p.c_rpi = NP; p.c_img_rows = S; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
     p.R2 = pos; p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
+    if (E->ln_fold) { p.C16 = A(E->Hn); p.row_stats = lnst; p.stats_nblk = ln_nblk; }
     exec_macs += (double)NP * D_VIT * Kp;
     cat_macs[0] += (double)NP * D_VIT * Kp;
     chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
   }
-  chk(launch_cls_rows(E->f(vp + "cls_token"), pos, X, B, S, D_VIT, st), "cls_rows");
+  chk(launch_cls_rows(E->mode_of(DPTX_GROUP_VIT), E->f(vp + "cls_token"), pos, X, B, S, D_VIT, E->ln_fold ? A(E->Hn) : nullptr,
+                      E->ln_fold ? lnst : nullptr, st),
+      "cls_rows");
   const int M = B * S;
   const size_t tok_elems = (size_t)M * D_VIT;
   auto tok_tap = [&](int idx, const char* name) {
@@ -774,12 +833,15 @@ int Run::forward(const void* x, void* y, void* y2) {
   };
   tok_tap(0, "tok0");
 
+  // ln: 0 plain; 1 consumer of the folded LayerNorm (qkv, fc1); 2 producer (proj, fc2: 16-bit copy + row statistics)
   auto dense = [&](const void* A, int a_fp32, const std::string& wkey, int N, int K, void* C, int c_fp32, const float* bias,
-                   int act, const void* R1, int r1_fp32) {
+                   int act, const void* R1, int r1_fp32, int ln = 0, const float* ln_colsum = nullptr) {
     GemmParams p;
     gemm_params_dense(p, M, N, K);
     p.A = A; p.a_fp32 = a_fp32; p.W = E->w(wkey); p.C = C; p.c_fp32 = c_fp32; p.bias = bias; p.act = act;
     p.R1 = R1; p.r1_fp32 = r1_fp32; p.planes = E->pl;
+    if (ln == 1) { p.ln_stats = lnst; p.ln_colsum = ln_colsum; p.ln_nblk = ln_nblk; p.ln_eps = 1e-6f; p.ln_inv_dim = 1.0f / (float)K; }
+    if (ln == 2) { p.C16 = this->A(E->Hn); p.row_stats = lnst; p.stats_nblk = ln_nblk; }
     exec_macs += (double)S * N * K;
     cat_macs[0] += (double)S * N * K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
@@ -794,8 +856,10 @@ int Run::forward(const void* x, void* y, void* y2) {
     chk(launch_readout_cls(dt, X, (long long)S * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT, D_VIT,
                            E->f(pp + "0.project.0.bias"), clsb, B, D_VIT, D_VIT, E->pl, st),
         "readout_cls");
-    // the token GEMM reads a 16-bit image of the fp32 stream (Hn is free between blocks)
-    chk(launch_cast_f32(dt, X, A(E->Hn), (size_t)B * S * D_VIT, E->pl, st), "readout_cast");
+    // the token GEMM reads a 16-bit image of the fp32 stream: with the LayerNorm fold the last fc2 epilogue has already
+    // written it (single-plane: the fold implies single-pass ViT blocks; a 3-MFMA reassemble group then still needs the
+    // lo plane, so it casts); otherwise Hn is free between blocks
+    if (!(E->ln_fold && !mode_is_x3(dt))) chk(launch_cast_f32(dt, X, A(E->Hn), (size_t)B * S * D_VIT, E->pl, st), "readout_cast");
     exec_macs += (double)D_VIT * D_VIT;  // per image
     void* R = (n & 1) ? A(E->R3) : A(E->R4);
     GemmParams p{};
@@ -835,15 +899,18 @@ int Run::forward(const void* x, void* y, void* y2) {
   for (int l = 0; l < E->depth; ++l) {
     group(DPTX_GROUP_VIT);
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
-    chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
-    dense(A(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, A(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0);
+    const bool lf = E->ln_fold;
+    if (!lf) chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
+    dense(A(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, A(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0, lf ? 1 : 0,
+          lf ? E->f(p + "attn.qkv.lnsum") : nullptr);
     chk(launch_attention(dt, A(E->QKV), A(E->AO), B, S, N_HEADS, E->pl, st), "attention", 1);
     exec_macs += 2.0 * N_HEADS * (double)S * S * 64;
     cat_macs[1] += 2.0 * N_HEADS * (double)S * S * 64;
-    dense(A(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1);
-    chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln2", 2);
-    dense(A(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, A(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0);
-    dense(A(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1);
+    dense(A(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1, lf ? 2 : 0);
+    if (!lf) chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln2", 2);
+    dense(A(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, A(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0, lf ? 1 : 0,
+          lf ? E->f(p + "mlp.fc1.lnsum") : nullptr);
+    dense(A(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1, lf ? 2 : 0);
     {
       char nm[16];
       snprintf(nm, sizeof nm, "blk%d", l);
@@ -974,7 +1041,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (cfg->backbone == DPTX_BACKBONE_VITL16_384 && cfg->dual_task) return DPTX_E_INVALID;  // the dual-task model is the hybrid
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
-      cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_FP8 || (cfg->ws_form != 0 && cfg->ws_form != 1))
+      cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_FP8 || (cfg->ws_form != 0 && cfg->ws_form != 1) ||
+      (cfg->flags & ~DPTX_FLAG_NO_LN_FOLD) || cfg->reserved != 0)
     return DPTX_E_INVALID;
   int x3_groups = 0;
   if (cfg->dtype == DPTX_DTYPE_MIXED) {
@@ -994,6 +1062,11 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   e->backbone = cfg->backbone;
   if (e->backbone == DPTX_BACKBONE_VITL16_384) { e->dv = 1024; e->dm = 4096; e->nh = 16; e->depth = 24; }
   e->max_h = max_h;
+  {
+    // fused schedules (include/dptx.h DPTX_FLAG_*; the environment variables are for A/B runs of one binary)
+    const char* t = getenv("DPTX_LN_FOLD");
+    e->ln_fold = !(cfg->flags & DPTX_FLAG_NO_LN_FOLD) && !(t && t[0] == '0') && !mode_is_x3(e->mode_of(DPTX_GROUP_VIT));
+  }
   {
     const char* t = getenv("DPTX_STREAMS");  // experiments: overrides cfg.streams
     const int ns = t ? atoi(t) : cfg->streams;

@@ -259,12 +259,21 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   // BPI: per-image bias 0 / 1 / -1) and selected by ONE uniform branch below: inside an instance the loads are
   // unconditional, so the compiler keeps them where they are written -- all up front -- instead of sinking each one
   // into the conditional block that consumes it (which serialises a memory latency per row).
-  auto body = [&](auto r1m_, auto r2m_, auto bpi_) {
+  auto body = [&](auto r1m_, auto r2m_, auto bpi_, auto lnf_) {
     constexpr int R1M = decltype(r1m_)::value, R2M = decltype(r2m_)::value, BPI = decltype(bpi_)::value;
+    constexpr bool LNF = decltype(lnf_)::value != 0;  // LayerNorm folded into this GEMM (consumer side, kernels.h)
+    float ln_c[8];  // colsum of the folded weight for this thread's 8 columns
+    if (LNF) {
+      const float4 c0 = *(const float4*)(p.ln_colsum + n), c1 = *(const float4*)(p.ln_colsum + n + 4);
+      ln_c[0] = c0.x; ln_c[1] = c0.y; ln_c[2] = c0.z; ln_c[3] = c0.w;
+      ln_c[4] = c1.x; ln_c[5] = c1.y; ln_c[6] = c1.z; ln_c[7] = c1.w;
+    }
+    float ln_mu[GR], ln_rs[GR];
     const bool r1 = R1M < 0 ? p.R1 != nullptr : R1M > 0, r2 = R2M < 0 ? p.R2 != nullptr : R2M > 0;
     const bool r1f = R1M < 0 ? p.r1_fp32 != 0 : R1M == 2, r2f = R2M < 0 ? p.r2_fp32 != 0 : R2M == 2;
     const bool bpi = BPI < 0 ? p.bias_per_img != 0 : BPI > 0;
     long long coff[GR];
+    int crow_[GR];  // C row (< 2^31) of the LayerNorm-fold statistics record
     bool ok[GR];
     u32x4_t ra[GR][2], rb[GR][2], bb[GR][2];
     // addresses and every global load of row group `gi` of slab `s`
@@ -286,6 +295,25 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         }
         const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
         coff[it] = crow * p.ldc + n;
+        crow_[it] = (int)crow;
+        if (LNF) {
+          // (mu, rstd) of GEMM row m from its per-128-column (sum, sum of squares) records: at most 8 records, read as
+          // float4 pairs; every thread of a row reads the same addresses (broadcast)
+          const float4* st = (const float4*)(p.ln_stats + (long long)m * p.ln_nblk * 2);
+          float sm = 0.f, sq = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (2 * j < p.ln_nblk) {
+              const float4 r = st[j];
+              sm += r.x + r.z;
+              sq += r.y + r.w;
+            }
+          const float mu = sm * p.ln_inv_dim;
+          // E[x^2] - mu^2 in double: the subtraction is where the bits would go
+          const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
+          ln_mu[it] = mu;
+          ln_rs[it] = 1.0f / sqrtf(fmaxf((float)var, 0.f) + p.ln_eps);
+        }
         if (r1) {
           if (r1f) {
             const u32x4_t* src = (const u32x4_t*)((const float*)p.R1 + coff[it]);
@@ -353,6 +381,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
           }
 #endif
+          if (LNF) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(-ln_mu[it], ln_c[e], v[e]) * ln_rs[it];
+          }
           if (bpi) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(bb[it][0][e]); v[4 + e] += __uint_as_float(bb[it][1][e]); }
@@ -389,7 +421,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
               for (int e = 0; e < 8; ++e) v[e] += f[e];
             }
           }
+          if (p.row_stats != nullptr) {  // LayerNorm fold, producer side: (sum, sum of squares) per 128-column block
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sm += v[e]; sq = fmaf(v[e], v[e], sq); }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }  // fixed order
+            if (ok[it] && (cn & 15) == 0)
+              ((float2*)p.row_stats)[(long long)crow_[it] * p.stats_nblk + ((n0 + cn * 8) >> 7)] = make_float2(sm, sq);
+          }
           if (ok[it]) {
+            if (p.C16 != nullptr) store8f<DT, 1>((uint16_t*)p.C16 + coff[it], 0, v);
             if (p.c_fp32) {
               float* cp = (float*)p.C + coff[it];
               *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
@@ -412,17 +454,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
     }
   };
   using std::integral_constant;
+  typedef integral_constant<int, 0> I0;
+  typedef integral_constant<int, 1> I1;
+  typedef integral_constant<int, 2> I2;
+  typedef integral_constant<int, -1> IX;
   const bool has1 = p.R1 != nullptr, has2 = p.R2 != nullptr;
-  if (!has1 && !has2 && !p.bias_per_img)
-    body(integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // qkv, fc1, most convs
-  else if (has1 && p.r1_fp32 && !has2 && !p.bias_per_img)
-    body(integral_constant<int, 2>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // proj, fc2: fp32 stream
-  else if (has1 && !p.r1_fp32 && !has2 && !p.bias_per_img)
-    body(integral_constant<int, 1>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});  // RCU conv2
-  else if (has1 && !p.r1_fp32 && has2 && !p.r2_fp32 && !p.bias_per_img)
-    body(integral_constant<int, 1>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{});  // RCU conv2 + path
-  else
-    body(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});  // patch-embed, readout
+  if (p.ln_stats != nullptr) body(I0{}, I0{}, I0{}, I1{});  // qkv, fc1 with the LayerNorm folded in (launch_gemm checks: no residuals)
+  else if (!has1 && !has2 && !p.bias_per_img) body(I0{}, I0{}, I0{}, I0{});  // qkv, fc1, most convs
+  else if (has1 && p.r1_fp32 && !has2 && !p.bias_per_img) body(I2{}, I0{}, I0{}, I0{});  // proj, fc2: fp32 stream
+  else if (has1 && !p.r1_fp32 && !has2 && !p.bias_per_img) body(I1{}, I0{}, I0{}, I0{});  // RCU conv2
+  else if (has1 && !p.r1_fp32 && has2 && !p.r2_fp32 && !p.bias_per_img) body(I1{}, I1{}, I0{}, I0{});  // RCU conv2 + path
+  else body(IX{}, IX{}, IX{}, I0{});  // patch-embed, readout
 }
 
 // ------------------------------------------------------------------- direct-to-LDS kernel
@@ -1067,9 +1109,14 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   } else if constexpr (PL == 1) {
     constexpr size_t smem1 = gemm_smem_bytes<BM, BN, 1>();
     if (p.a_fp32) {
-      auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, true>;
-      set_smem_attr(k, smem1);
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, q);
+      // fp32 A exists for dense GEMMs with wide outputs only (the 256-row tiles serve N = 32 / 64 convolutions; their
+      // fp32-staging variant would hold 64 staging + 64 accumulator + 48 fragment registers and spill)
+      if constexpr (BM == 256) return hipErrorInvalidValue;
+      else {
+        auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, true>;
+        set_smem_attr(k, smem1);
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem1, stream, q);
+      }
     } else {
       auto k = gemm_reg_kernel<DT, BM, BN, WM_, WN_, false>;
       set_smem_attr(k, smem1);
@@ -1116,9 +1163,10 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
     // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md)
     if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200) return launch_cfg<DT, PL, 128, 128, 2, 4>(p, stream);
   }
+  // (row_stats -- the producer side of the LayerNorm fold -- reduces 128-column blocks inside a tile: never narrower tiles)
   // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
   // 128x64 by 2..10 %, whose second round is nearly empty
-  if (p.N % 128 == 0 && m128 * (p.N / 128) >= 256) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
+  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
   if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1>(p, stream);
   if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 256, 64, 4, 1>(p, stream);
   if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);

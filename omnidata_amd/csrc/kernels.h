@@ -51,6 +51,21 @@ struct GemmParams {
   void* C8;
   int q_relu;
   float out_scale;
+  // LayerNorm folded into the GEMMs around it (timm Block: x += proj(attn(norm1(x))); x += fc2(gelu(fc1(norm2(x))))):
+  //  * PRODUCER side (patch-embed, proj, fc2 -- the launches that write the fp32 token stream): C16 = 16-bit copy of the
+  //    final output rows (the next GEMM's A operand), row_stats = per (C row, 128-column block) float2 (sum, sum of
+  //    squares) of the fp32 output, [rows][stats_nblk]; needs N % 128 == 0 and a tile at least 128 columns wide.
+  //  * CONSUMER side (qkv, fc1): A is that 16-bit copy of the UN-normalised stream, W = gamma (.) W and bias = W beta + b
+  //    were folded at pack time, ln_colsum[n] = sum_k W'[n][k] (of the ROUNDED operand values, so that the mean
+  //    component cancels exactly), and the epilogue applies  y = (acc - mu * colsum) * rstd + bias  with (mu, rstd) of
+  //    GEMM row m combined from ln_stats[m][0..ln_nblk).
+  void* C16;
+  float* row_stats;
+  int stats_nblk;
+  const float* ln_stats;
+  const float* ln_colsum;
+  int ln_nblk;
+  float ln_eps, ln_inv_dim;
   long long* trace;  // debug: s_memtime stamps of block 0 (dptx_debug_set_trace); null in production
   float a_rpi_rcp, wout_rcp;  // 1 / a_rpi, 1 / Wout (filled in by launch_gemm: row -> (image, y, x) without integer division)
 };
@@ -107,7 +122,9 @@ hipError_t launch_head_out(int mode, const void* X, const float* w, const float*
 hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
                             void* y, int io, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream);
 hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, int gw, int C, hipStream_t stream);
-hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, int S, int C, hipStream_t stream);
+// X16 / stats (optional, LayerNorm fold): 16-bit copy of the rows and their (sum, sum of squares) per 128-column block
+hipError_t launch_cls_rows(int mode, const float* cls, const float* pos, float* X, int B, int S, int C, void* X16, float* stats,
+                           hipStream_t stream);
 
 // out[b][n] = bias[n] + sum_k x[b*x_stride + k] * W[n*ldw + w_off + k]   (x fp32, W 16-bit, out fp32)
 hipError_t launch_readout_cls(int mode, const float* x, long long x_stride, const void* W, int ldw, int w_off,

@@ -100,15 +100,40 @@ hipError_t launch_head_out(int mode, const void* X, const float* w, const float*
 
 // ------------------------------------------------------------------------------- cls rows
 // vit.py:141-147: x = cat(cls, patches) + pos_embed  ->  X[b*S + 0] = cls + pos[0]
-__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X, int B,
-                                int S, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  X[(long long)b * S * C + c] = cls[c] + pos[c];
+// one block per image, 128 threads per 128-column block of the row (C % 128 == 0)
+template <int DT>
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X, int S, int C,
+                                uint16_t* __restrict__ X16, float* __restrict__ stats) {
+  __shared__ float red[2][16];
+  const int b = blockIdx.x;
+  const int nblk = C >> 7;
+  for (int c0 = 0; c0 < C; c0 += blockDim.x) {  // blockDim.x is a multiple of 128
+    const int c = c0 + threadIdx.x;
+    float v = 0.f;
+    if (c < C) {
+      v = cls[c] + pos[c];
+      X[(long long)b * S * C + c] = v;
+      if (X16) X16[(long long)b * S * C + c] = T16<DT>::fromf(v);
+    }
+    if (stats) {  // fixed-order reduction: wave sums, then the two waves of a 128-column block
+      const float sm = wave_sum(v), sq = wave_sum(v * v);
+      const int w = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) { red[0][w] = sm; red[1][w] = sq; }
+      __syncthreads();
+      if ((threadIdx.x & 127) == 0 && c < C)
+        ((float2*)stats)[(long long)b * S * nblk + (c >> 7)] = make_float2(red[0][w] + red[0][w + 1], red[1][w] + red[1][w + 1]);
+      __syncthreads();
+    }
+  }
 }
-hipError_t launch_cls_rows(const float* cls, const float* pos, float* X, int B, int S, int C, hipStream_t stream) {
-  hipLaunchKernelGGL(cls_rows_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, cls, pos, X, B, S, C);
+hipError_t launch_cls_rows(int mode, const float* cls, const float* pos, float* X, int B, int S, int C, void* X16, float* stats,
+                           hipStream_t stream) {
+  if (C % 128 != 0) return hipErrorInvalidValue;
+  const int nt = C >= 1024 ? 1024 : (C >= 256 ? 256 : 128);
+  if (mode == MODE_FP16 || mode == MODE_FP16X3)
+    hipLaunchKernelGGL(cls_rows_kernel<DT_FP16>, dim3(B), dim3(nt), 0, stream, cls, pos, X, S, C, (uint16_t*)X16, stats);
+  else
+    hipLaunchKernelGGL(cls_rows_kernel<DT_BF16>, dim3(B), dim3(nt), 0, stream, cls, pos, X, S, C, (uint16_t*)X16, stats);
   return hipGetLastError();
 }
 

@@ -35,7 +35,7 @@ class DptxConfig(C.Structure):
                 ("device_id", C.c_int32), ("non_negative", C.c_int32), ("ws_form", C.c_int32),
                 ("ws_eps", C.c_float), ("max_height", C.c_int32), ("max_width", C.c_int32),
                 ("dual_task", C.c_int32), ("streams", C.c_int32), ("x3_groups", C.c_int32), ("backbone", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 # (name, restype, argtypes) for every symbol declared in include/dptx.h
@@ -132,7 +132,7 @@ class Engine:
     def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "bf16",
                  device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8,
                  max_hw: Tuple[int, int] = (384, 384), dual: bool = False, streams: int = 0, x3_groups=0,
-                 backbone: str = "vitb_rn50_384"):
+                 backbone: str = "vitb_rn50_384", flags: int = 0):
         self.lib = load_library()
         cfg = DptxConfig()
         self.lib.dptx_default_config(C.byref(cfg))
@@ -144,6 +144,7 @@ class Engine:
         cfg.streams = int(streams)
         cfg.x3_groups = groups_mask(x3_groups)  # dtype "mixed": groups that run 3 MFMAs per product (0 = all but the ViT blocks)
         cfg.backbone = BACKBONE_IDS[backbone]
+        cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold)
         self.cfg = cfg
         self.dtype = dtype
         self.backbone = backbone

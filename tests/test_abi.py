@@ -79,6 +79,11 @@ def _blob_offsets(spec_items, dtype_bytes=2):
             b = n * 4
         out[k] = (off, b)
         off += (b + 255) // 256 * 256
+        if k.endswith("mlp.fc2.bias"):  # derived entries of the LayerNorm fold (engine.hip R_DERIVED): column sums of W'
+            blk = k[:-len("mlp.fc2.bias")]
+            for name, m in ((blk + "attn.qkv.lnsum", 3 * n), (blk + "mlp.fc1.lnsum", 4 * n)):
+                out[name] = (off, m * 4)
+                off += (m * 4 + 255) // 256 * 256
     return out, off
 
 
@@ -88,12 +93,33 @@ def test_packed_weights_match_numpy_fold(built_lib, dtype):
     from oracle.dpt_oracle import standardize_weight
     C = 1
     sd = random_state_dict(3, C)
-    e = Engine(num_channels=C, max_batch=2, dtype=dtype, device_id=None)
+    e = Engine(num_channels=C, max_batch=2, dtype=dtype, device_id=None, flags=1)  # DPTX_FLAG_NO_LN_FOLD: weights as loaded
     e.load_state_dict(sd)
     blob = e.export_packed_host()
     offs, total = _blob_offsets(state_dict_spec(C).items())
     assert total == blob.size == e.packed_bytes
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    # default engine: LayerNorm folded into qkv / fc1 -- W' = W diag(gamma) rounded, b' = b + W beta, lnsum = row sums of the
+    # ROUNDED W' (what the MFMA multiplies the mean with)
+    ef = Engine(num_channels=C, max_batch=2, dtype=dtype, device_id=None)
+    ef.load_state_dict(sd)
+    fblob = ef.export_packed_host()
+    assert fblob.size == blob.size
+    for wk, nk in (("attn.qkv", "norm1"), ("mlp.fc1", "norm2")):
+        pre = "pretrained.model.blocks.7."
+        W, g_, b_ = sd[pre + wk + ".weight"], sd[pre + nk + ".weight"], sd[pre + nk + ".bias"]
+        o, nb = offs[pre + wk + ".weight"]
+        got = torch.from_numpy(fblob[o:o + nb].copy()).view(tdt).float().reshape(W.shape)
+        assert torch.equal(got, (W * g_[None, :]).to(tdt).float())
+        o, nb = offs[pre + wk + ".lnsum"]
+        cs = torch.from_numpy(fblob[o:o + nb].copy()).view(torch.float32)
+        assert torch.allclose(cs.double(), got.double().sum(1), rtol=1e-6, atol=1e-6)
+        o, nb = offs[pre + wk + ".bias"]
+        bb = torch.from_numpy(fblob[o:o + nb].copy()).view(torch.float32)
+        assert torch.allclose(bb.double(), sd[pre + wk + ".bias"].double() + W.double() @ b_.double(), rtol=1e-6, atol=1e-6)
+    # everything the fold does not touch is identical in both blobs
+    o, nb = offs["pretrained.model.blocks.7.attn.proj.weight"]
+    assert np.array_equal(blob[o:o + nb], fblob[o:o + nb])
 
     def packed16(key, n):
         o, b = offs[key]
@@ -152,7 +178,7 @@ def test_bf16x3_packing_has_hi_and_lo_planes(built_lib):
     """bf16x3 blob = [hi blob | lo blob]: hi is exactly the bf16 blob, lo = bf16(w - hi)."""
     from omnidata_amd.engine import Engine
     sd = random_state_dict(4, 3)
-    e1 = Engine(num_channels=3, max_batch=1, dtype="bf16", device_id=None)
+    e1 = Engine(num_channels=3, max_batch=1, dtype="bf16", device_id=None, flags=1)  # no LayerNorm fold: bf16x3 never folds
     e1.load_state_dict(sd)
     e3 = Engine(num_channels=3, max_batch=1, dtype="bf16x3", device_id=None)
     e3.load_state_dict(sd)

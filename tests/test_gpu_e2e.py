@@ -250,3 +250,36 @@ def test_packed_blob_cache_roundtrip(tmp_path):
     b.load_packed(path)
     x = synthetic_input(1, 2, "depth").to(DEV)
     assert torch.equal(a.forward(x), b.forward(x))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "mixed"])
+def test_layernorm_fold_matches_separate_layernorm(dtype):
+    """The LayerNorm of the ViT blocks is folded into the qkv / fc1 GEMMs (include/dptx.h DPTX_FLAG_NO_LN_FOLD; the row
+    statistics and the 16-bit operand copy of the fp32 token stream come out of the preceding proj / fc2 / patch-embed
+    epilogue).  Both schedules are the same arithmetic up to WHERE the 16-bit rounding of the qkv / fc1 operand happens
+    (before vs after the normalisation), so they must agree far inside the dtype's budget against the oracle, every token
+    tap included -- a wrong mean / rstd / column sum shows up at blk0 at once."""
+    from omnidata_amd.engine import Engine
+    sd, x, ref, otaps = oracle_case("normal", 3, 0, 2)
+    taps, outs = {}, {}
+    for flags in (0, 1):
+        eng = Engine(num_channels=3, max_batch=2, dtype=dtype, device_id=0, flags=flags)
+        eng.load_state_dict(sd)
+        eng.enable_taps(True)
+        outs[flags] = eng.forward(x.to(DEV)).cpu()
+        taps[flags] = {n: eng.tap(n) for n in ("tok0", "blk0", "blk5", "blk11", "l3", "l4")}
+        eng.close()
+    assert torch.equal(taps[0]["tok0"], taps[1]["tok0"])   # the stream itself is written identically
+    step = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11, "mixed": 2.0 ** -11}[dtype]
+    for n in ("blk0", "blk5", "blk11", "l3", "l4"):
+        a, b, want = taps[0][n], taps[1][n], otaps[n]
+        rel_ab = ((a - b).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+        rel_a = ((a - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+        rel_b = ((b - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+        print(f"    [{dtype}] tap {n:6s} fold vs separate {rel_ab:.3e}; vs oracle: fold {rel_a:.3e} separate {rel_b:.3e}")
+        assert rel_ab < 12 * step, n          # a handful of operand roundings apart
+        assert rel_a < 3 * rel_b + 4 * step, n   # and the fold is not markedly less accurate
+    d0, d1 = (outs[0] - ref).abs().max().item(), (outs[1] - ref).abs().max().item()
+    print(f"    [{dtype}] out max|d| vs oracle: fold {d0:.3e} separate {d1:.3e}")
+    bar = {"bf16": E2E_TOL["bf16"][0], "fp16": E2E_TOL["fp16"][0], "mixed": 1e-3}[dtype]
+    assert d0 < bar

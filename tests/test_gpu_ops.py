@@ -127,16 +127,22 @@ def test_conv_halo_resident(dtype, case):
 
 
 def test_conv_halo_resident_in_child():
+    """The halo kernel is an EXPERIMENT (csrc/experiments/): it exists only in a library built with
+    DPTX_CXXFLAGS=-DDPTX_EXPERIMENTS DPTX_LIB_SUFFIX=_exp (omnidata_amd/build.py); the default libdptx.so neither contains
+    it nor reads DPTX_HALO.  Skipped unless that library has been built next to the default one."""
     import subprocess
     import sys
+    exp_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omnidata_amd", "libdptx_exp.so")
+    if not os.path.exists(exp_lib):
+        pytest.skip("experiments library not built (DPTX_CXXFLAGS=-DDPTX_EXPERIMENTS DPTX_LIB_SUFFIX=_exp python -m omnidata_amd.build)")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__ + "::test_conv_halo_resident"],
-                       env=dict(os.environ, DPTX_HALO="1"), capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, DPTX_HALO="1", DPTX_LIB=exp_lib), capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,S", [(1, 577), (3, 577), (2, 64), (1, 200)])
+@pytest.mark.parametrize("B,S", [(1, 577), (3, 577), (2, 64), (1, 200), (2, 65), (1, 66), (2, 17), (1, 129)])
 def test_attention(dtype, B, S):
     lib = load_library()
     H = 12
@@ -145,6 +151,7 @@ def test_attention(dtype, B, S):
     q3 = qkv.view(B, S, 3, H, 64)
     q3[:, S // 2, 1] *= 6.0
     q3[:, S - 1, 1] *= 4.0
+    q3[0, 0, 1, ::2] *= 5.0   # key 0 (the cls token) is handled outside the key tiles: make it dominate for some heads
     out = torch.empty(B * S, H * 64, device=DEV, dtype=TDT[dtype])
     assert lib.dptx_op_attention(DTYPES[dtype], ptr(qkv), ptr(out), B, S, H, stream()) == 0
     q, k, v = [t.permute(0, 2, 1, 3).float() for t in q3.unbind(2)]
