@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--backbone", default="vitb_rn50_384", choices=["vitb_rn50_384", "vitl16_384"],
                     help="vitb_rn50_384 = DPT-Hybrid (BASELINE.json's configuration, the default); vitl16_384 = DPT-Large")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the short secondary measurements (depth, dual-task bf16 / fp8) "
+                                                            "that the default N = 1 normal-head run appends under 'also'")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (functional test of the N>1 path)")
@@ -149,14 +151,21 @@ def main():
         # figure is the committed rocprofv3 measurement of this very command (profiles/README.md), scaled
         # from its batch to this one; null when no measurement is committed for the dtype.
         traffic = None
-        for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json"):  # newest committed round wins
+        for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json"):  # newest committed round wins
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and args.dtype == "bf16" and not large:
                 tj = json.load(open(tpath))
                 traffic = round(tj["gemm_family_hbm_bytes_per_launch"] * args.batch / 32.0)
+        # the fraction is quoted for the single-pass 16-bit modes only: fp8 runs part of the family on the 2x-rate e4m3 MFMA
+        # and the 3-MFMA modes execute up to three products per algorithmic one, so "achieved / bf16 peak" would not be a
+        # utilisation figure there
+        single_pass = args.dtype in ("bf16", "fp16")
         roofline = {"bound": "mfma", "kernel": "dptx::gemm_kernel (implicit-GEMM MFMA, all conv/linear launches)",
                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(achieved / PEAK_TFLOPS, 4) if single_pass else None,
+                    "frac_note": None if single_pass else "not quoted: algorithmic FLOP/s of a mode that runs part of the family on "
+                                 "the fp8 MFMA (2x peak) or with 3 MFMAs per product is not a utilisation of the bf16 peak",
+                    "traffic": traffic,
                     "traffic_note": "HBM bytes per gemm launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from the committed "
                                     "rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json, newest round); algorithmic min ~ A+C+W bytes",
                     "launches_per_step": acc["gemm"][1], "avg_launch_ms": round(gemm_ms / max(1, acc["gemm"][1]), 5),
@@ -238,6 +247,40 @@ def main():
                                      "meets_1e-3": bool(pm < 1e-3)}
             pe.close()
 
+    # ---- BASELINE.json configs[2] and configs[4] next to the headline (configs[1]): short runs of the depth head and of the
+    # dual-task forward (bf16 and with the fp8 decoder) under the same protocol, so that the driver's one default call sees them
+    also = None
+    if rank == 0 and world == 1 and not args.no_also and args.task == "normal" and not large and args.dtype == "bf16":
+        from omnidata_amd.engine import Engine
+        also = []
+        for task2, dtype2, cfg_i in (("depth", "bf16", 2), ("dual", "bf16", 4), ("dual", "fp8", 4)):
+            d2 = task2 == "dual"
+            C2 = 1 if task2 == "depth" else 3
+            e2 = Engine(num_channels=C2, max_batch=args.batch, dtype=dtype2, device_id=local_rank, dual=d2)
+            e2.load_state_dict(random_dual_state_dict(0) if d2 else random_state_dict(0, C2))
+            x2 = synthetic_input(1000, args.batch, "normal" if d2 else task2).to(device).to(io_dt)
+            ya = torch.empty(args.batch, C2, 384, 384, dtype=io_dt, device=device)
+            yb = torch.empty(args.batch, 1, 384, 384, dtype=io_dt, device=device)
+            f2 = (lambda: e2.forward_dual(x2, out_normal=ya, out_depth=yb)) if d2 else (lambda: e2.forward(x2, out=ya))
+            n2 = max(4, min(args.steps, 10))
+            for _ in range(3):
+                f2()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n2):
+                f2()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            also.append({"workload": f"DPT-Hybrid-384 {task2}, batch {args.batch}, {dtype2}, 1xMI355X (BASELINE.json configs[{cfg_i}])",
+                         "task": task2, "dtype": dtype2, "value": round(args.batch * n2 / dt2, 2), "unit": "images/s",
+                         "steps": n2, "ms_per_step": round(1e3 * dt2 / n2, 3),
+                         "e2e_tflops_algorithmic": round(args.batch * n2 / dt2 * GFLOP_PER_IMAGE[task2] / 1e3, 1),
+                         "accuracy_note": None if dtype2 != "fp8" else "throughput mode with its own tolerance "
+                                          "(tests/test_gpu_fp8.py); NOT validated on the published checkpoints"})
+            e2.close()
+            del e2, x2, ya, yb
+            torch.cuda.empty_cache()
+
     if rank == 0:
         total_images = args.batch * world * args.steps
         value = total_images / elapsed
@@ -256,9 +299,9 @@ def main():
                                       f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])"), "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"replicas x{world} (no collective in the loop)",
                        "schedule": "each forward = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)"},
-            "e2e_mfma_frac": round(e2e_tflops / (PEAK_TFLOPS * world), 4),
+            "e2e_mfma_frac": round(e2e_tflops / (PEAK_TFLOPS * world), 4) if args.dtype in ("bf16", "fp16") else None,
             "e2e_tflops_algorithmic": round(e2e_tflops, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "kernel_breakdown": breakdown,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "also": also, "kernel_breakdown": breakdown,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

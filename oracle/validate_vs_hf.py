@@ -25,7 +25,7 @@ from oracle.dpt_oracle import dpt_forward  # noqa: E402
 from omnidata_amd.weights import random_state_dict, synthetic_input  # noqa: E402
 
 
-def to_hf(sd):
+def to_hf(sd, hybrid=True):
     out = {}
     vp = "pretrained.model."
     for k, v in sd.items():
@@ -42,7 +42,8 @@ def to_hf(sd):
                 r = "encoder." + r.replace(".blocks.", ".layers.")
             out["dpt.embeddings.backbone.bit." + r] = v
         elif k.startswith(vp + "patch_embed.proj."):
-            out["dpt.embeddings.projection." + k.rsplit(".", 1)[1]] = v
+            # hybrid: 1x1 projection of the ResNet map; DPT-Large: timm PatchEmbed = HF DPTViTPatchEmbeddings
+            out[("dpt.embeddings.projection." if hybrid else "dpt.embeddings.patch_embeddings.projection.") + k.rsplit(".", 1)[1]] = v
         elif k.startswith(vp + "blocks."):
             _, _, _, l, rest = k.split(".", 4)
             p = f"dpt.encoder.layer.{l}."
@@ -90,6 +91,37 @@ def to_hf(sd):
     return out
 
 
+def main_large():
+    """DPT-Large (`backbone='vitl16_384'`): the restated timm `vit_large_patch16_384` + the reference-side
+    reassemble stages (ConvTranspose2d k4s4 / k2s2, identity, conv3x3 s2) of oracle.dpt_forward_vitl16 against HuggingFace
+    `DPTForDepthEstimation(is_hybrid=False)` on the same seeded weights."""
+    from transformers import DPTConfig, DPTForDepthEstimation
+    from oracle.dpt_oracle import dpt_forward_vitl16
+    torch.set_num_threads(os.cpu_count())
+    cfg = DPTConfig(is_hybrid=False, image_size=384, patch_size=16, hidden_size=1024, num_hidden_layers=24,
+                    num_attention_heads=16, intermediate_size=4096, hidden_act="gelu", layer_norm_eps=1e-6, qkv_bias=True,
+                    backbone_out_indices=[5, 11, 17, 23], neck_hidden_sizes=[256, 512, 1024, 1024],
+                    reassemble_factors=[4, 2, 1, 0.5], readout_type="project", fusion_hidden_size=256, head_in_index=-1,
+                    use_batch_norm_in_fusion_residual=False, add_projection=False, hidden_dropout_prob=0.0,
+                    attention_probs_dropout_prob=0.0)
+    hf = DPTForDepthEstimation(cfg).eval()
+    worst = 0.0
+    for seed in (5,):
+        sd = random_state_dict(seed, 1, backbone="vitl16_384")
+        missing, unexpected = hf.load_state_dict(to_hf(sd, hybrid=False), strict=False)
+        unexpected = [u for u in unexpected if "fusion_stage.layers.0.residual_layer1" not in u]
+        assert not missing and not unexpected, (missing, unexpected)
+        x = synthetic_input(seed, 1, "depth")
+        with torch.no_grad():
+            y_hf = hf(pixel_values=x).predicted_depth
+        y = dpt_forward_vitl16(sd, x)
+        d = (y_hf - y).abs().max().item()
+        worst = max(worst, d)
+        print(f"DPT-Large seed={seed}: |HF(is_hybrid=False) - oracle.dpt_forward_vitl16|={d:.3e}  out std={y_hf.std():.3f}")
+    assert worst < 5e-4, worst
+    return worst
+
+
 def main():
     from transformers import DPTConfig, DPTForDepthEstimation
     torch.set_num_threads(os.cpu_count())
@@ -125,3 +157,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_large()
