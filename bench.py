@@ -112,6 +112,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.dtype == "fp8":  # per-tensor activation scales of the e4m3 copies: rank 0 measures them on its batch
+        from omnidata_amd.dist import broadcast_fp8_calibration
+        broadcast_fp8_calibration(eng, x, device)
     for _ in range(args.warmup):
         eng.forward(x, out=y)
     sync_all()
@@ -261,6 +264,8 @@ def main():
             x2 = synthetic_input(1000, args.batch, "normal" if d2 else task2).to(device).to(io_dt)
             ya = torch.empty(args.batch, C2, 384, 384, dtype=io_dt, device=device)
             yb = torch.empty(args.batch, 1, 384, 384, dtype=io_dt, device=device)
+            if dtype2 == "fp8":
+                e2.calibrate_fp8(x2)
             f2 = (lambda: e2.forward_dual(x2, out_normal=ya, out_depth=yb)) if d2 else (lambda: e2.forward(x2, out=ya))
             n2 = max(4, min(args.steps, 10))
             for _ in range(3):

@@ -168,6 +168,22 @@ int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_d
 int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_normal_dev, void* y_depth_dev,
                       int32_t batch, int32_t height, int32_t width, void* stream);
 
+/* fp8 dtype: activation scales.  Every tensor that has an e4m3 copy (the inputs of the decoder's fp8 convolutions) is
+ * quantised as e4m3(x * s) with a per-tensor power-of-two scale s; e4m3 covers 2^-9 .. 448, so with s = 1 (a fresh handle)
+ * activations beyond 448 saturate and activations below 2^-9 vanish.  dptx_calibrate_fp8 runs ONE forward of the given
+ * batch with the decoder convolutions on their bf16 operands, measures max |x| of every such tensor and sets s so that
+ * the maximum lands in (112, 224] (one binade of headroom); the results y (and y2 for a dual-task handle, else NULL) are
+ * the bf16-decoder results of that batch.  Call it once after loading weights, on a representative batch, before the
+ * first dptx_forward.  The reference has no counterpart (it has no fp8 path); weights are quantised per output channel
+ * at dptx_finalize_weights. */
+int dptx_calibrate_fp8(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, void* y2_dev,
+                       int32_t batch, int32_t height, int32_t width, void* stream);
+/* Number of e4m3 tensors of the last forward (<= 128); copies their scales / calibration max |x| (either may be NULL).
+ * dptx_fp8_set_calibration installs scales measured elsewhere (rank 0 calibrates, the others receive: positive powers of
+ * two, slot order = launch order of the forward). */
+int dptx_fp8_get_calibration(dptx_handle h, float* scales, float* amax, int32_t capacity);
+int dptx_fp8_set_calibration(dptx_handle h, const float* scales, int32_t n);
+
 /* Debug hook for stage-level parity (SURVEY.md A.1 tap names: "stem","s0","s1","s2","tok0",
  * "blk0".."blk11","l3","l4","l1_rn".."l4_rn","p4","p3","p2","p1","h0","h1").  Copies the
  * stage activation of the LAST forward, converted to fp32 in the engine's internal layout

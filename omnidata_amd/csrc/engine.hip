@@ -230,6 +230,8 @@ std::vector<Spec> build_spec(int C, bool dual, int backbone) {
     }
   }
   }  // backbone
+  // "<conv>.f8scale": per-output-channel inverse of the power-of-two scale the e4m3 copy of the weight was quantised with
+  // (fp8 dtype; derived at pack time, zero otherwise)
   auto decoder = [&](const std::string& pre, int ch) {
     const int rn_in[4] = {256, 512, D_VIT, D_VIT};
     for (int i = 1; i <= 4; ++i) add(v, pre + "scratch.layer" + std::to_string(i) + "_rn.weight", {FEAT, rn_in[i - 1], 3, 3}, R_CONV);
@@ -237,16 +239,19 @@ std::vector<Spec> build_spec(int C, bool dual, int backbone) {
       const std::string p = pre + "scratch.refinenet" + std::to_string(i) + ".";
       add(v, p + "out_conv.weight", {FEAT, FEAT, 1, 1}, R_CONV);
       add(v, p + "out_conv.bias", {FEAT}, R_VEC);
+      add(v, p + "out_conv.f8scale", {FEAT}, R_DERIVED);
       for (int u = 1; u <= 2; ++u)
         for (int c = 1; c <= 2; ++c) {
           const bool unused = (i == 4 && u == 1);  // blocks.py:329-333: resConfUnit1 needs two inputs
           const std::string q = p + "resConfUnit" + std::to_string(u) + ".conv" + std::to_string(c) + ".";
           add(v, q + "weight", {FEAT, FEAT, 3, 3}, unused ? R_UNUSED : R_CONV);
           add(v, q + "bias", {FEAT}, unused ? R_UNUSED : R_VEC);
+          if (!unused) add(v, q + "f8scale", {FEAT}, R_DERIVED);
         }
     }
     add(v, pre + "scratch.output_conv.0.weight", {FEAT / 2, FEAT, 3, 3}, R_CONV);
     add(v, pre + "scratch.output_conv.0.bias", {FEAT / 2}, R_VEC);
+    add(v, pre + "scratch.output_conv.0.f8scale", {FEAT / 2}, R_DERIVED);
     add(v, pre + "scratch.output_conv.2.weight", {32, FEAT / 2, 3, 3}, R_CONV);
     add(v, pre + "scratch.output_conv.2.bias", {32}, R_VEC);
     add(v, pre + "scratch.output_conv.4.weight", {ch, 32, 1, 1}, R_HEAD4);
@@ -337,10 +342,18 @@ struct dptx_engine {
            (key.find("resConfUnit") != std::string::npos || key.find("out_conv") != std::string::npos ||
             key.find("output_conv.0.") != std::string::npos);
   }
-  std::vector<float> w_scale;  // per spec entry: 1 / (power-of-two scale applied before e4m3 quantisation); 0 = no fp8 copy
-  size_t scale_table_off() const { return 2 * packed_single; }
   const void* w8(const std::string& key) const { return d_blob + packed_single + packed_off.at(key) / 2; }
-  float wscale(const std::string& key) const { return w_scale[spec_index.at(key)]; }
+  // per-output-channel inverse weight scales of an fp8 conv ("....weight" -> "....f8scale" entry of the blob)
+  const float* wscale(const std::string& key) const { return f(key.substr(0, key.size() - 6) + "f8scale"); }
+  // fp8 activation scales: every tensor that has an e4m3 copy gets a power-of-two scale s (the copy holds e4m3(x * s), the
+  // consuming conv multiplies its accumulators by 1 / s), indexed by the order in which a forward produces the copies.
+  // 1.0 until dptx_calibrate_fp8 has measured the tensors' max |x| on a calibration batch (slot -> max |x| in act_amax).
+  static constexpr int MAX_Q8 = 128;
+  std::vector<float> act_scale = std::vector<float>(MAX_Q8, 1.0f);
+  std::vector<float> act_amax = std::vector<float>(MAX_Q8, 0.0f);
+  int n_q8 = 0;                  // slots used by the last forward
+  bool calibrating = false, calibrated = false;
+  unsigned* d_amax = nullptr;    // [MAX_Q8] float bits (calibration forwards only)
   void* q8(const void* p) const { return d_arena + arena_single + ((const char*)p - d_arena) / 2; }  // e4m3 copy of an arena tensor
   // fused head tail (head.hip): single-plane head, no stage taps wanted; DPTX_HEAD_FUSED=0 keeps the three launches
   bool head_fused() const {
@@ -478,7 +491,6 @@ int pack_host(dptx_engine* e) {
   e->host_blob.assign(e->packed_bytes, 0);
   const bool bf = e->bf16_storage();
   const bool x3 = e->two_planes() && !e->fp8();
-  e->w_scale.assign(e->spec.size(), 0.f);
   const size_t lo_elems = e->packed_single / 2;  // uint16 distance hi -> lo plane
   auto bf16_to_f32 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
   // writes element i of a 16-bit tensor (and its lo plane in bf16x3 mode)
@@ -589,28 +601,30 @@ int pack_host(dptx_engine* e) {
   }
   if (e->fp8()) {
     // e4m3 copies of the fp8 layers' weights (same [O][kh][kw][I] order as the bf16 copy, one byte per element, second
-    // plane of the blob) quantised after a per-layer power-of-two scale that puts max|w| in [224, 448); the GEMM epilogue
-    // multiplies by its inverse.  The inverses travel in a table behind the two planes (ranks that import the blob).
+    // plane of the blob), quantised per OUTPUT CHANNEL after a power-of-two scale that puts the channel's max |w| into
+    // (224, 448] (e4m3 tops out at 448); the inverses go to the layer's "f8scale" vector, which the
+    // GEMM epilogue multiplies the accumulators with.
     for (size_t si = 0; si < e->spec.size(); ++si) {
       const Spec& sp = e->spec[si];
       if (sp.role != R_CONV || !dptx_engine::fp8_weight(sp.key)) continue;
-      const size_t n = numel(sp.shape), off = e->packed_off.at(sp.key);
+      const size_t off = e->packed_off.at(sp.key);
       const std::vector<float>& src = e->staged.at(sp.key);
       const int O = (int)sp.shape[0], I = (int)sp.shape[1], KH = (int)sp.shape[2], KW = (int)sp.shape[3];
-      float mx = 0.f;
-      for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(src[i]));
-      const int k = mx > 0.f ? (int)std::floor(std::log2(224.0 / (double)mx)) : 0;
-      const float sc = std::ldexp(1.0f, k);
+      const size_t per_o = (size_t)I * KH * KW;
       uint8_t* d8 = e->host_blob.data() + e->packed_single + off / 2;
-      for (int o = 0; o < O; ++o)
+      float* inv = (float*)(e->host_blob.data() + e->packed_off.at(sp.key.substr(0, sp.key.size() - 6) + "f8scale"));
+      for (int o = 0; o < O; ++o) {
+        float mx = 0.f;
+        for (size_t i = 0; i < per_o; ++i) mx = std::max(mx, std::fabs(src[(size_t)o * per_o + i]));
+        const int k = mx > 0.f ? (int)std::floor(std::log2(448.0 / (double)mx)) : 0;
+        const float sc = std::ldexp(1.0f, k);
         for (int ky = 0; ky < KH; ++ky)
           for (int kx = 0; kx < KW; ++kx)
             for (int i = 0; i < I; ++i)
-              d8[(size_t)o * I * KH * KW + ((size_t)ky * KW + kx) * I + i] =
-                  f32_to_e4m3(src[(((size_t)o * I + i) * KH + ky) * KW + kx] * sc);
-      e->w_scale[si] = 1.0f / sc;
+              d8[(size_t)o * per_o + ((size_t)ky * KW + kx) * I + i] = f32_to_e4m3(src[(((size_t)o * I + i) * KH + ky) * KW + kx] * sc);
+        inv[o] = 1.0f / sc;
+      }
     }
-    memcpy(e->host_blob.data() + e->scale_table_off(), e->w_scale.data(), e->w_scale.size() * 4);
   }
   e->finalized = true;
   return DPTX_OK;
@@ -630,6 +644,23 @@ struct Run {
   const char* where = "";
   int64_t launches = 0;    // accounting of this run (copied to the engine by the caller)
   double exec_macs = 0.0, cat_macs[4] = {0, 0, 0, 0};
+  // fp8: slot (dptx_engine::act_scale index) of the latest e4m3 copy of an arena buffer; slots count up in launch order
+  std::unordered_map<const void*, int> q8_slot;
+  int q8_count = 0;
+  int q8_produce(const void* out) {
+    const int slot = q8_count < dptx_engine::MAX_Q8 ? q8_count : dptx_engine::MAX_Q8 - 1;
+    ++q8_count;
+    q8_slot[out] = slot;
+    return slot;
+  }
+  float q8_scale_of(const void* in) const {
+    auto it = q8_slot.find(in);
+    return it == q8_slot.end() ? 1.0f : e->act_scale[it->second];
+  }
+  // calibration forwards (dptx_calibrate_fp8) measure max |x| of every tensor that gets an e4m3 copy
+  void q8_measure(const void* out, size_t n, int relu, int slot) {
+    if (e->calibrating && e->d_amax) chk(launch_amax(MODE_BF16, out, n, relu, e->d_amax + slot, st), "fp8.amax");
+  }
 
   char* A(const Buf& b) const { return e->d_arena + abase + (half ? b.off2 : b.off); }
 
@@ -661,10 +692,16 @@ struct Run {
             const void* R2 = nullptr, float* gn_part = nullptr, int q = 0) {
     // fp8 dtype: q = 1 / 2 also writes the e4m3 copy of the output (2: ReLU'd, for consumers that pre-activate); a conv
     // whose weight has an e4m3 copy runs on the fp8 MFMA, reading the e4m3 copy of `in` (ReLU'd by its producer)
-    const bool f8 = e->fp8() && dptx_engine::fp8_weight(wkey);
+    // (a calibration forward runs these convs on their bf16 operands: a saturated e4m3 copy upstream must not distort the
+    // max |x| measured downstream)
+    const bool f8 = e->fp8() && dptx_engine::fp8_weight(wkey) && !e->calibrating;
     GemmParams p{};
     p.A = in; p.W = e->w(wkey); p.C = out; p.bias = bias; p.R1 = R1; p.R2 = R2;
-    if (e->fp8() && q) { p.C8 = e->q8(out); p.q_relu = q == 2; }
+    int slot = -1;
+    if (e->fp8() && q) {
+      slot = q8_produce(out);
+      p.C8 = e->q8(out); p.q_relu = q == 2; p.q_scale = e->act_scale[slot];
+    }
     p.M = B * Hout * Wout; p.N = Cout; p.K = ksz * ksz * Cin; p.ldw = p.K;
     p.a_rpi = Hout * Wout; p.Wout = Wout; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.a_pix_stride = Cin;
     p.a_img_stride = (long long)Hin * Win * Cin; p.a_off = 0;
@@ -675,11 +712,13 @@ struct Run {
     p.k_tap_fast = (ksz == 3 && Cin >= 512) ? 1 : 0;  // measured per layer: profiles/r01_experiments.md
     if (gn_part) { p.gn_part = gn_part; p.gn_hw = Hout * Wout; p.gn_blocks = Hout * Wout / 32; p.gn_cpg = Cout / 32; }
     if (f8) {
-      p.A = e->q8(in); p.W = e->w8(wkey); p.a_bytes /= 2; p.a_relu = 0; p.out_scale = e->wscale(wkey);
+      p.A = e->q8(in); p.W = e->w8(wkey); p.a_bytes /= 2; p.a_relu = 0;
+      p.out_scale = 1.0f / q8_scale_of(in); p.out_scale_v = e->wscale(wkey);
     }
     exec_macs += (double)p.M / B * p.N * p.K;
     cat_macs[0] += (double)p.M / B * p.N * p.K;
     chk(launch_gemm(f8 ? MODE_FP8 : dt, p, st), wkey.c_str(), 0);
+    if (slot >= 0) q8_measure(out, (size_t)p.M * p.N, q == 2, slot);
   }
 
   // GroupNorm statistics come out of the producing conv's epilogue when an image's rows are whole 32-row MFMA blocks
@@ -801,7 +840,7 @@ int Run::forward(const void* x, void* y, void* y2) {
   // LayerNorm fold (kernels.h GemmParams::ln_stats): every launch that writes the fp32 token stream also writes its 16-bit
   // copy into Hn and the per-row (sum, sum of squares) records into lnst; qkv / fc1 read Hn and normalise in the epilogue
   float* lnst = (float*)A(E->lnst);
-  const int ln_nblk = D_VIT / 128;
+  const int ln_nblk = D_VIT / 128;  // records per token row (6 or 8; the row stride is always 8)
   group(DPTX_GROUP_EMBED);
   {
     // hybrid: the 1x1 projection of the ResNet's 1/16-resolution map (K = 1024); DPT-Large: timm PatchEmbed, a 16x16
@@ -815,7 +854,7 @@ int Run::forward(const void* x, void* y, void* y2) {
     p.bias = E->f(vp + "patch_embed.proj.bias");
     p.c_rpi = NP; p.c_img_rows = S; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
     p.R2 = pos; p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
-    if (E->ln_fold) { p.C16 = A(E->Hn); p.row_stats = lnst; p.stats_nblk = ln_nblk; }
+    if (E->ln_fold) { p.C16 = A(E->Hn); p.row_stats = lnst; p.stats_nblk = 8; }
     exec_macs += (double)NP * D_VIT * Kp;
     cat_macs[0] += (double)NP * D_VIT * Kp;
     chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
@@ -841,7 +880,7 @@ int Run::forward(const void* x, void* y, void* y2) {
     p.A = A; p.a_fp32 = a_fp32; p.W = E->w(wkey); p.C = C; p.c_fp32 = c_fp32; p.bias = bias; p.act = act;
     p.R1 = R1; p.r1_fp32 = r1_fp32; p.planes = E->pl;
     if (ln == 1) { p.ln_stats = lnst; p.ln_colsum = ln_colsum; p.ln_nblk = ln_nblk; p.ln_eps = 1e-6f; p.ln_inv_dim = 1.0f / (float)K; }
-    if (ln == 2) { p.C16 = this->A(E->Hn); p.row_stats = lnst; p.stats_nblk = ln_nblk; }
+    if (ln == 2) { p.C16 = this->A(E->Hn); p.row_stats = lnst; p.stats_nblk = 8; }
     exec_macs += (double)S * N * K;
     cat_macs[0] += (double)S * N * K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
@@ -960,8 +999,14 @@ int Run::forward(const void* x, void* y, void* y2) {
     rcu(p + "resConfUnit2.", sum, h, w, A(E->tA), A(E->tC), nullptr, 1);
     conv(A(E->tC), h, w, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, w, FEAT, A(E->tA), E->f(p + "out_conv.bias"), 0, 0);
     // path_1 feeds the first head conv: in the fp8 dtype the up-sampling also writes its e4m3 copy
-    chk(launch_upsample2x(dt, A(E->tA), A(E->P[i - 1]), B, h, w, FEAT, E->pl, st, (E->fp8() && i == 1) ? E->q8(A(E->P[0])) : nullptr),
-        "fusion.up");
+    {
+      const bool up8 = E->fp8() && i == 1;
+      const int slot = up8 ? q8_produce(A(E->P[0])) : -1;
+      chk(launch_upsample2x(dt, A(E->tA), A(E->P[i - 1]), B, h, w, FEAT, E->pl, st, up8 ? E->q8(A(E->P[0])) : nullptr,
+                            up8 ? E->act_scale[slot] : 1.0f),
+          "fusion.up");
+      if (up8) q8_measure(A(E->P[0]), (size_t)B * 4 * h * w * FEAT, 0, slot);
+    }
     path = A(E->P[i - 1]);
     tap((pre + p_names[i - 1]).c_str(), path, 2 * h, 2 * w, FEAT);
   }
@@ -996,6 +1041,7 @@ int Run::forward(const void* x, void* y, void* y2) {
     for (const char* n : {"l1_rn", "l2_rn", "l3_rn", "l4_rn", "p1", "p2", "p3", "p4", "h0", "h1"}) E->taps.erase(n);
     decode("depth.", 1, y2);
   }
+  E->n_q8 = q8_count < dptx_engine::MAX_Q8 ? q8_count : dptx_engine::MAX_Q8;
   if (err != hipSuccess) return E->fail(DPTX_E_HIP, std::string("launch failed at ") + where + ": " + hipGetErrorString(err));
   return DPTX_OK;
 }
@@ -1085,7 +1131,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
     }
   }
   e->packed_single = off;
-  e->packed_bytes = off * (e->two_planes() ? 2 : 1) + (e->fp8() ? align_up(e->spec.size() * 4, 256) : 0);
+  e->packed_bytes = off * (e->two_planes() ? 2 : 1);
   e->pl.w = e->two_planes() ? (long long)(off / 2) : 0;
   plan_arena(e);
   if (cfg->device_id >= 0) {
@@ -1107,6 +1153,7 @@ void dptx_destroy(dptx_handle h) {
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
+    if (h->d_amax) (void)hipFree(h->d_amax);
     for (auto ev : h->events) (void)hipEventDestroy(ev);
     for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
       if (h->sub_stream[r]) (void)hipStreamDestroy(h->sub_stream[r]);
@@ -1187,12 +1234,6 @@ int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, 
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
   HIPCHK(h, hipMemcpyAsync(h->d_blob, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  if (h->fp8()) {  // the per-layer output scales are launch parameters: read them back from the blob's table
-    h->w_scale.assign(h->spec.size(), 0.f);
-    HIPCHK(h, hipMemcpyAsync(h->w_scale.data(), h->d_blob + h->scale_table_off(), h->spec.size() * 4, hipMemcpyDeviceToHost,
-                             (hipStream_t)stream));
-    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
-  }
   h->device_ready = true;
   return DPTX_OK;
 }
@@ -1220,7 +1261,7 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
                        hipStream_t stream) {
   const int C = h->cfg.num_channels;
   const size_t esz = io == DPTX_IO_FP32 ? 4 : 2;  // bytes per element of the caller's buffers
-  const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling;
+  const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling && !h->calibrating;
   if (!split) {
     Run run{h, batch, stream, h->cfg.dtype, height, width, io};
     const int rc = run.forward(x, y, y2);
@@ -1305,6 +1346,67 @@ int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
   return run_forward(h, x_dev, x_dtype, y_normal_dev, y_depth_dev, batch, height, width, (hipStream_t)stream);
+}
+
+int dptx_calibrate_fp8(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, void* y2_dev, int32_t batch, int32_t height,
+                       int32_t width, void* stream) {
+  if (!h || !x_dev || !y_dev) return DPTX_E_INVALID;
+  if (!h->fp8()) return h->fail(DPTX_E_INVALID, "dptx_calibrate_fp8 needs a handle created with dtype = DPTX_DTYPE_FP8");
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "dptx_calibrate_fp8 on a host-only handle");
+  if (!h->device_ready) return h->fail(DPTX_E_INVALID, "dptx_calibrate_fp8 before weights were finalized/imported");
+  if (batch < 1 || batch > h->cfg.max_batch) return h->fail(DPTX_E_INVALID, "batch out of range [1, max_batch]");
+  if (x_dtype != DPTX_IO_FP32 && x_dtype != DPTX_IO_BF16 && x_dtype != DPTX_IO_FP16) return h->fail(DPTX_E_INVALID, "unsupported x_dtype");
+  if (height < 64 || width < 64 || height % 32 != 0 || width % 32 != 0 || (long long)height * width > (long long)h->max_h * h->max_w)
+    return h->fail(DPTX_E_INVALID, "input height/width must be multiples of 32, >= 64, within the planned size");
+  if ((h->cfg.dual_task != 0) != (y2_dev != nullptr)) return h->fail(DPTX_E_INVALID, "y2_dev: the depth output of a dual-task handle");
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
+  hipStream_t st = (hipStream_t)stream;
+  if (!h->d_amax) HIPCHK(h, hipMalloc((void**)&h->d_amax, dptx_engine::MAX_Q8 * sizeof(unsigned)));
+  HIPCHK(h, hipMemsetAsync(h->d_amax, 0, dptx_engine::MAX_Q8 * sizeof(unsigned), st));
+  h->calibrating = true;
+  const int rc = run_forward(h, x_dev, x_dtype, y_dev, y2_dev, batch, height, width, st);
+  h->calibrating = false;
+  if (rc != DPTX_OK) return rc;
+  unsigned bits[dptx_engine::MAX_Q8];
+  HIPCHK(h, hipMemcpyAsync(bits, h->d_amax, sizeof bits, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  for (int i = 0; i < dptx_engine::MAX_Q8; ++i) {
+    float a;
+    memcpy(&a, &bits[i], 4);
+    h->act_amax[i] = a;
+    // power of two that puts the calibration maximum into (112, 224]: one binade of headroom below e4m3's 448
+    int k = (a > 0.f && std::isfinite(a)) ? (int)std::floor(std::log2(224.0 / (double)a)) : 0;
+    k = k < -24 ? -24 : (k > 24 ? 24 : k);
+    h->act_scale[i] = std::ldexp(1.0f, k);
+  }
+  h->calibrated = true;
+  return DPTX_OK;
+}
+
+int dptx_fp8_get_calibration(dptx_handle h, float* scales, float* amax, int32_t capacity) {
+  if (!h) return DPTX_E_INVALID;
+  if (!h->fp8()) return h->fail(DPTX_E_INVALID, "not an fp8 handle");
+  const int n = h->n_q8;
+  if (capacity < n) return h->fail(DPTX_E_INVALID, "capacity < number of e4m3 tensors of the last forward");
+  for (int i = 0; i < n; ++i) {
+    if (scales) scales[i] = h->act_scale[i];
+    if (amax) amax[i] = h->act_amax[i];
+  }
+  return n;
+}
+
+int dptx_fp8_set_calibration(dptx_handle h, const float* scales, int32_t n) {
+  if (!h || !scales || n < 0 || n > dptx_engine::MAX_Q8) return DPTX_E_INVALID;
+  if (!h->fp8()) return h->fail(DPTX_E_INVALID, "not an fp8 handle");
+  for (int i = 0; i < n; ++i) {
+    int e2 = 0;
+    const float m = std::frexp(scales[i], &e2);
+    if (!(scales[i] > 0.f) || m != 0.5f) return h->fail(DPTX_E_INVALID, "activation scales must be positive powers of two");
+    h->act_scale[i] = scales[i];
+  }
+  h->calibrated = true;
+  return DPTX_OK;
 }
 
 int dptx_tap(dptx_handle h, const char* name, float* dst_host, size_t capacity_floats, int64_t shape4[4]) {

@@ -248,6 +248,16 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
     bias_c[0] = b0.x; bias_c[1] = b0.y; bias_c[2] = b0.z; bias_c[3] = b0.w;
     bias_c[4] = b1.x; bias_c[5] = b1.y; bias_c[6] = b1.z; bias_c[7] = b1.w;
   }
+  float osc[8];  // fp8: output scale of this thread's 8 columns
+  if (p.out_scale != 0.f) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) osc[e] = p.out_scale;
+    if (p.out_scale_v != nullptr) {
+      const float4 s0 = *(const float4*)(p.out_scale_v + n), s1 = *(const float4*)(p.out_scale_v + n + 4);
+      osc[0] *= s0.x; osc[1] *= s0.y; osc[2] *= s0.z; osc[3] *= s0.w;
+      osc[4] *= s1.x; osc[5] *= s1.y; osc[6] *= s1.z; osc[7] *= s1.w;
+    }
+  }
   const bool remap = p.c_rpi != 0x7fffffff;  // token-row remap (patch-embed, readout); everything else skips the division
   // rows per load group: 4 (96 registers of loads in flight at most); 2 for the slab epilogue, whose 128 accumulator
   // registers stay live across the slabs
@@ -268,7 +278,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       ln_c[0] = c0.x; ln_c[1] = c0.y; ln_c[2] = c0.z; ln_c[3] = c0.w;
       ln_c[4] = c1.x; ln_c[5] = c1.y; ln_c[6] = c1.z; ln_c[7] = c1.w;
     }
-    float ln_mu[GR], ln_rs[GR];
+    float4 ln_rec[GR][4];
     const bool r1 = R1M < 0 ? p.R1 != nullptr : R1M > 0, r2 = R2M < 0 ? p.R2 != nullptr : R2M > 0;
     const bool r1f = R1M < 0 ? p.r1_fp32 != 0 : R1M == 2, r2f = R2M < 0 ? p.r2_fp32 != 0 : R2M == 2;
     const bool bpi = BPI < 0 ? p.bias_per_img != 0 : BPI > 0;
@@ -297,22 +307,12 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         coff[it] = crow * p.ldc + n;
         crow_[it] = (int)crow;
         if (LNF) {
-          // (mu, rstd) of GEMM row m from its per-128-column (sum, sum of squares) records: at most 8 records, read as
-          // float4 pairs; every thread of a row reads the same addresses (broadcast)
-          const float4* st = (const float4*)(p.ln_stats + (long long)m * p.ln_nblk * 2);
-          float sm = 0.f, sq = 0.f;
+          // the (sum, sum of squares) records of GEMM row m (row stride 8 records, ln_nblk = 6 or 8 of them valid), read as float4 pairs (every thread of a row
+          // reads the same addresses: broadcast).  Only the loads are issued here; they are combined where the row is
+          // written (a wait in this place would serialise a memory latency per row group)
+          const float4* st = (const float4*)(p.ln_stats + (long long)m * 16);  // row stride 8 records; ln_nblk (6 or 8) are valid
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (2 * j < p.ln_nblk) {
-              const float4 r = st[j];
-              sm += r.x + r.z;
-              sq += r.y + r.w;
-            }
-          const float mu = sm * p.ln_inv_dim;
-          // E[x^2] - mu^2 in double: the subtraction is where the bits would go
-          const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
-          ln_mu[it] = mu;
-          ln_rs[it] = 1.0f / sqrtf(fmaxf((float)var, 0.f) + p.ln_eps);
+          for (int j = 0; j < 4; ++j) ln_rec[it][j] = st[j];
         }
         if (r1) {
           if (r1f) {
@@ -375,15 +375,22 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
             v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
           }
-#ifndef DPTX_NO_F8EPI   // A/B builds: what do the fp8 hooks cost the 16-bit kernels?
-          if (p.out_scale != 0.f) {  // fp8 GEMMs: the weights were scaled by a power of two before quantisation
+          if (p.out_scale != 0.f) {  // fp8 GEMMs: weights (per output channel) and activations were scaled by powers of two
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+            for (int e = 0; e < 8; ++e) v[e] *= osc[e];
           }
-#endif
           if (LNF) {
+            const bool all8 = p.ln_nblk == 8;  // D = 1024; D = 768 has 6 records (the last float4 of the row is not written)
+            const float sm = (ln_rec[it][0].x + ln_rec[it][0].z) + (ln_rec[it][1].x + ln_rec[it][1].z) +
+                             ((ln_rec[it][2].x + ln_rec[it][2].z) + (all8 ? ln_rec[it][3].x + ln_rec[it][3].z : 0.f));
+            const float sq = (ln_rec[it][0].y + ln_rec[it][0].w) + (ln_rec[it][1].y + ln_rec[it][1].w) +
+                             ((ln_rec[it][2].y + ln_rec[it][2].w) + (all8 ? ln_rec[it][3].y + ln_rec[it][3].w : 0.f));
+            const float mu = sm * p.ln_inv_dim;
+            // E[x^2] - mu^2 in double: the subtraction is where the bits would go
+            const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
+            const float rs = __builtin_amdgcn_rsqf(fmaxf((float)var, 0.f) + p.ln_eps);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaf(-ln_mu[it], ln_c[e], v[e]) * ln_rs[it];
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(-mu, ln_c[e], v[e]) * rs;
           }
           if (bpi) {
 #pragma unroll
@@ -439,15 +446,16 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             } else {
               store8f<DT, PL>((uint16_t*)p.C + coff[it], p.planes.act, v);
             }
-#ifndef DPTX_NO_F8EPI
             if (p.C8 != nullptr) {  // e4m3 copy for an fp8 consumer (ReLU'd first when every consumer pre-activates)
+              const float qs = p.q_scale != 0.f ? p.q_scale : 1.0f;
               if (p.q_relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
               }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= qs;
               *(uint2*)((uint8_t*)p.C8 + coff[it]) = pack_fp8x8(v);
             }
-#endif
           }
         }
       }

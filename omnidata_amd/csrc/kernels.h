@@ -45,20 +45,24 @@ struct GemmParams {
   // of (sum, sum of squares) per 32-row block; gn_hw = rows per image (% 32 == 0), gn_cpg = N / 32 channels per group
   float* gn_part;
   int gn_hw, gn_blocks, gn_cpg;
-  // fp8 (MODE_FP8: A and W are e4m3 bytes, K and ldw count bytes): C *= out_scale before the bias (0 = none); C8: optional
-  // e4m3 copy of the final output (same addressing as C, 1 byte per element), ReLU'd first when q_relu -- also available
-  // to the 16-bit modes (the producers of an fp8 GEMM's input run in bf16)
+  // fp8 (MODE_FP8: A and W are e4m3 bytes, K and ldw count bytes): C *= out_scale * out_scale_v[n] before the bias
+  // (out_scale 0 = none; out_scale_v: optional per-output-channel vector -- the inverse of the power-of-two scale the
+  // weights of channel n were quantised with; out_scale then carries the inverse of the activation scale).  C8: optional
+  // e4m3 copy of the final output times q_scale (0 = 1.0; same addressing as C, 1 byte per element), ReLU'd first when
+  // q_relu -- also available to the 16-bit modes (the producers of an fp8 GEMM's input run in bf16)
   void* C8;
   int q_relu;
-  float out_scale;
+  float out_scale, q_scale;
+  const float* out_scale_v;
   // LayerNorm folded into the GEMMs around it (timm Block: x += proj(attn(norm1(x))); x += fc2(gelu(fc1(norm2(x))))):
   //  * PRODUCER side (patch-embed, proj, fc2 -- the launches that write the fp32 token stream): C16 = 16-bit copy of the
   //    final output rows (the next GEMM's A operand), row_stats = per (C row, 128-column block) float2 (sum, sum of
-  //    squares) of the fp32 output, [rows][stats_nblk]; needs N % 128 == 0 and a tile at least 128 columns wide.
+  //    squares) of the fp32 output, [rows][stats_nblk = 8] (row stride; N / 128 of them are written); needs
+  //    N % 128 == 0, N <= 1024 and a tile at least 128 columns wide.
   //  * CONSUMER side (qkv, fc1): A is that 16-bit copy of the UN-normalised stream, W = gamma (.) W and bias = W beta + b
   //    were folded at pack time, ln_colsum[n] = sum_k W'[n][k] (of the ROUNDED operand values, so that the mean
   //    component cancels exactly), and the epilogue applies  y = (acc - mu * colsum) * rstd + bias  with (mu, rstd) of
-  //    GEMM row m combined from ln_stats[m][0..ln_nblk).
+  //    GEMM row m combined from the records ln_stats[m][0..ln_nblk) (ln_nblk = 6 or 8, row stride 8).
   void* C16;
   float* row_stats;
   int stats_nblk;
@@ -109,9 +113,11 @@ hipError_t launch_stem_conv(int mode, const void* x, int io, const void* Wt, voi
                             hipStream_t stream);
 
 // bilinear x2 align_corners=True on NHWC 16-bit
-// Y8 (optional): e4m3 copy of the output, 1 byte per element, for an fp8 convolution downstream
+// Y8 (optional): e4m3 copy of the output times q_scale, 1 byte per element, for an fp8 convolution downstream
 hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream,
-                             void* Y8 = nullptr);
+                             void* Y8 = nullptr, float q_scale = 1.0f);
+// fp8 calibration: atomicMax(*amax_bits, bits of max |x| (relu: max(x, 0)) over n 16-bit elements); *amax_bits starts at 0
+hipError_t launch_amax(int mode, const void* X, size_t n, int relu, unsigned* amax_bits, hipStream_t stream);
 
 // y NCHW fp32 [B,Cout,HW] = act( W[Cout][32] * x[B*HW,32] + b ),  Cout <= 4
 hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, void* y, int io, int B, int HW,

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -29,8 +30,8 @@ void ensure_dyn_smem(const void* kernel, size_t bytes) {
 // per-thread index math is shifts and masks.
 template <int DT, int PL>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y,
-                                                         uint8_t* __restrict__ Y8, int B, int H, int W, int C, int cshift,
-                                                         long long plane) {
+                                                         uint8_t* __restrict__ Y8, float q_scale, int B, int H, int W, int C,
+                                                         int cshift, long long plane) {
   const int Ho = 2 * H, Wo = 2 * W, cvec = C >> 3;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Wo * cvec) return;
@@ -52,18 +53,49 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restr
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = bilerp(a[e], bb[e], c[e], d[e], lx0, lx1, ly0, ly1);
   store8f<DT, PL>(Y + ((long long)blockIdx.y * Wo + ox) * C + v * 8, plane, o);
-  if (Y8 != nullptr) *(uint2*)(Y8 + ((long long)blockIdx.y * Wo + ox) * C + v * 8) = pack_fp8x8(o);  // e4m3 copy for an fp8 conv
+  if (Y8 != nullptr) {  // e4m3 copy for an fp8 conv (times the tensor's calibrated power-of-two scale)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= q_scale;
+    *(uint2*)(Y8 + ((long long)blockIdx.y * Wo + ox) * C + v * 8) = pack_fp8x8(o);
+  }
 }
 
 hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream,
-                             void* Y8) {
+                             void* Y8, float q_scale) {
   const int cvec = C / 8;
   if (C % 8 != 0 || (cvec & (cvec - 1)) != 0 || (long long)H * W * C >= (1ll << 31)) return hipErrorInvalidValue;
   int cshift = 0;
   while ((1 << cshift) < cvec) ++cshift;
   dim3 grid((2 * W * cvec + 255) / 256, B * 2 * H);
   DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((upsample2x_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X,
-                                              (uint16_t*)Y, (uint8_t*)Y8, B, H, W, C, cshift, pl.act));
+                                              (uint16_t*)Y, (uint8_t*)Y8, q_scale, B, H, W, C, cshift, pl.act));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ fp8 calibration
+// max |x| (relu: max(x, 0)) of a 16-bit tensor; non-negative floats order like their bit patterns, so one atomicMax on
+// the bits per block is the whole cross-block reduction
+template <int DT>
+__global__ __launch_bounds__(256) void amax_kernel(const uint16_t* __restrict__ X, size_t n8, int relu, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float f[8];
+    unpack8<DT>(*(const uint4*)(X + i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, relu ? f[e] : fabsf(f[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+hipError_t launch_amax(int mode, const void* X, size_t n, int relu, unsigned* amax_bits, hipStream_t stream) {
+  if (n % 8 != 0) return hipErrorInvalidValue;
+  const size_t n8 = n / 8;
+  const int grid = (int)std::min<size_t>((n8 + 255) / 256, 4096);
+  if (mode == MODE_FP16 || mode == MODE_FP16X3)
+    hipLaunchKernelGGL(amax_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, n8, relu, amax_bits);
+  else
+    hipLaunchKernelGGL(amax_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)X, n8, relu, amax_bits);
   return hipGetLastError();
 }
 
@@ -106,7 +138,6 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
                                 uint16_t* __restrict__ X16, float* __restrict__ stats) {
   __shared__ float red[2][16];
   const int b = blockIdx.x;
-  const int nblk = C >> 7;
   for (int c0 = 0; c0 < C; c0 += blockDim.x) {  // blockDim.x is a multiple of 128
     const int c = c0 + threadIdx.x;
     float v = 0.f;
@@ -121,7 +152,7 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
       if ((threadIdx.x & 63) == 0) { red[0][w] = sm; red[1][w] = sq; }
       __syncthreads();
       if ((threadIdx.x & 127) == 0 && c < C)
-        ((float2*)stats)[(long long)b * S * nblk + (c >> 7)] = make_float2(red[0][w] + red[0][w + 1], red[1][w] + red[1][w + 1]);
+        ((float2*)stats)[(long long)b * S * 8 + (c >> 7)] = make_float2(red[0][w] + red[0][w + 1], red[1][w] + red[1][w + 1]);
       __syncthreads();
     }
   }

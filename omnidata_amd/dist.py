@@ -31,6 +31,22 @@ def broadcast_blob(blob: Optional[torch.Tensor], nbytes: int, device: torch.devi
     return t
 
 
+def broadcast_fp8_calibration(eng, x: Optional[torch.Tensor], device: torch.device, src: int = 0):
+    """fp8 dtype: `src` measures the activation scales of the e4m3 tensors on its batch `x` (Engine.calibrate_fp8) and every
+    rank installs the same 128 power-of-two scales -- one small broadcast at start-up, none in the loop."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        eng.calibrate_fp8(x)
+        return
+    t = torch.ones(128, dtype=torch.float32, device=device)
+    if dist.get_rank() == src:
+        eng.calibrate_fp8(x)
+        s, _ = eng.fp8_calibration()
+        t[: len(s)] = torch.from_numpy(s).to(device)
+    dist.broadcast(t, src=src)
+    if dist.get_rank() != src:
+        eng.set_fp8_calibration(t.cpu().numpy())
+
+
 def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dtype: str, device_index: int, src: int = 0,
                             dual: bool = False, x3_groups=0, backbone: str = "vitb_rn50_384"):
     """Every rank gets an Engine with identical packed weights; only `src` runs the host-side

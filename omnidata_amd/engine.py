@@ -54,6 +54,9 @@ ABI = [
     ("dptx_forward", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
     ("dptx_forward_hw", C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_forward_dual", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("dptx_calibrate_fp8", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("dptx_fp8_get_calibration", C.c_int, [_vp, _f32p, _f32p, _i32]),
+    ("dptx_fp8_set_calibration", C.c_int, [_vp, _f32p, _i32]),
     ("dptx_tap", C.c_int, [_vp, C.c_char_p, _vp, _sz, _i64p]),
     ("dptx_enable_taps", C.c_int, [_vp, C.c_int]),
     ("dptx_forward_info", C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -146,6 +149,7 @@ class Engine:
         cfg.backbone = BACKBONE_IDS[backbone]
         cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold)
         self.cfg = cfg
+        self.fp8_calibrated = False
         self.dtype = dtype
         self.backbone = backbone
         self.h = _vp()
@@ -272,6 +276,38 @@ class Engine:
         self._check(self.lib.dptx_forward_dual(self.h, x.data_ptr(), IO_DTYPES[x.dtype], out_normal.data_ptr(), out_depth.data_ptr(), B, H, W,
                                                _stream(x.device)), "forward_dual")
         return out_normal, out_depth
+
+    # ---- fp8 dtype: per-tensor activation scales (include/dptx.h dptx_calibrate_fp8)
+    def calibrate_fp8(self, x: torch.Tensor):
+        """Measures max |x| of every tensor that gets an e4m3 copy on this batch (one forward with a bf16 decoder) and sets
+        the tensors' power-of-two scales.  Returns that forward's result(s)."""
+        if not x.is_cuda:
+            raise RuntimeError("dptx needs a CUDA(HIP) tensor; there is no CPU fallback")
+        if x.dtype not in IO_DTYPES:
+            x = x.float()
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        dual = bool(self.cfg.dual_task)
+        y = torch.empty(B, 3 if dual else self.cfg.num_channels, H, W, dtype=x.dtype, device=x.device)
+        y2 = torch.empty(B, 1, H, W, dtype=x.dtype, device=x.device) if dual else None
+        self._check(self.lib.dptx_calibrate_fp8(self.h, x.data_ptr(), IO_DTYPES[x.dtype], y.data_ptr(), _ptr(y2), B, H, W,
+                                                _stream(x.device)), "calibrate_fp8")
+        self.fp8_calibrated = True
+        return (y, y2) if dual else y
+
+    def fp8_calibration(self):
+        """(scales, max |x|) of the e4m3 tensors of the last forward, in launch order."""
+        s = np.zeros(128, dtype=np.float32)
+        a = np.zeros(128, dtype=np.float32)
+        n = self.lib.dptx_fp8_get_calibration(self.h, s.ctypes.data_as(_f32p), a.ctypes.data_as(_f32p), 128)
+        if n < 0:
+            self._check(n, "fp8_get_calibration")
+        return s[:n].copy(), a[:n].copy()
+
+    def set_fp8_calibration(self, scales):
+        s = np.ascontiguousarray(scales, dtype=np.float32)
+        self._check(self.lib.dptx_fp8_set_calibration(self.h, s.ctypes.data_as(_f32p), int(s.size)), "fp8_set_calibration")
+        self.fp8_calibrated = True
 
     def enable_taps(self, on: bool = True):
         self._check(self.lib.dptx_enable_taps(self.h, int(on)), "enable_taps")

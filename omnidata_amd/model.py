@@ -125,6 +125,13 @@ class DPTDepthModel(BaseModel):
         self._engine_key = (device_index, self._weights_version, self.engine_dtype, self._chunk(), self.max_hw)
 
     @torch.no_grad()
+    def calibrate(self, x: torch.Tensor):
+        """dtype='fp8' only: (re-)measures the activation ranges of the e4m3 tensors on `x` (at most max_batch images)."""
+        if self.engine_dtype != "fp8":
+            raise RuntimeError("calibrate() applies to dtype='fp8'")
+        self._get_engine(x.device).calibrate_fp8(x[: self._chunk()])
+
+    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("omnidata_amd.DPTDepthModel runs only on an AMD GPU (HIP); got a CPU tensor. "
@@ -136,6 +143,10 @@ class DPTDepthModel(BaseModel):
             self.max_hw = (H, W)  # re-plans the arena (and re-packs the weights) once for the larger size
         eng = self._get_engine(x.device)
         step = self._chunk()
+        if self.engine_dtype == "fp8" and not eng.fp8_calibrated:
+            # per-tensor activation scales of the e4m3 copies: measured once, on the first batch this model sees
+            # (include/dptx.h dptx_calibrate_fp8; call model.calibrate(x) with a representative batch to choose it)
+            eng.calibrate_fp8(x[:step])
         if B <= step:
             y = eng.forward(x)
         else:
@@ -225,6 +236,8 @@ class DPTDualTaskModel(nn.Module):
             self.max_hw = (H, W)
         eng = self._get_engine(x.device)
         step = self._chunk()
+        if self.engine_dtype == "fp8" and not eng.fp8_calibrated:
+            eng.calibrate_fp8(x[:step])  # activation scales of the e4m3 tensors, measured on the first batch
         yn = torch.empty(B, 3, H, W, dtype=_io_dtype(x), device=x.device)
         yd = torch.empty(B, 1, H, W, dtype=_io_dtype(x), device=x.device)
         for i in range(0, B, step):

@@ -79,11 +79,15 @@ def _blob_offsets(spec_items, dtype_bytes=2):
             b = n * 4
         out[k] = (off, b)
         off += (b + 255) // 256 * 256
-        if k.endswith("mlp.fc2.bias"):  # derived entries of the LayerNorm fold (engine.hip R_DERIVED): column sums of W'
+        derived = []  # entries the engine computes at pack time (engine.hip R_DERIVED)
+        if k.endswith("mlp.fc2.bias"):  # LayerNorm fold: column sums of the folded qkv / fc1 weights
             blk = k[:-len("mlp.fc2.bias")]
-            for name, m in ((blk + "attn.qkv.lnsum", 3 * n), (blk + "mlp.fc1.lnsum", 4 * n)):
-                out[name] = (off, m * 4)
-                off += (m * 4 + 255) // 256 * 256
+            derived = [(blk + "attn.qkv.lnsum", 3 * n), (blk + "mlp.fc1.lnsum", 4 * n)]
+        elif k.endswith(".bias") and ("scratch.refinenet" in k or "scratch.output_conv.0." in k):
+            derived = [(k[:-len("bias")] + "f8scale", n)]  # fp8 dtype: per-output-channel inverse weight scales
+        for name, m in derived:
+            out[name] = (off, m * 4)
+            off += (m * 4 + 255) // 256 * 256
     return out, off
 
 

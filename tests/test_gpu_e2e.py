@@ -171,7 +171,7 @@ def test_input_contract_errors():
     y = model(torch.zeros(1, 3, 384, 384, device=DEV))
     assert y.shape == (1, 384, 384)
     n, alg, exe = model.engine.info()
-    assert n > 200 and abs(alg - 127.615e9) < 1e6 and 120e9 < exe < 130e9
+    assert 150 < n < 300 and abs(alg - 127.615e9) < 1e6 and 120e9 < exe < 130e9  # 199 launches (225 without the LayerNorm fold)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
