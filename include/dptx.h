@@ -95,8 +95,11 @@ typedef struct dptx_config {
 /* dptx_config.flags.  NO_LN_FOLD: keep the 24 LayerNorm launches of the ViT blocks instead of folding the LayerNorm into
  * the qkv / fc1 GEMMs (gamma into W, W beta into the bias, (x W' - mu colsum(W')) rstd in the epilogue; row statistics and
  * the 16-bit operand copy of the fp32 token stream come out of the preceding proj / fc2 / patch-embed epilogue).  The fold
- * applies to single-pass ViT blocks only (bf16, fp16, fp8, and mixed policies without DPTX_GROUP_VIT). */
-enum { DPTX_FLAG_NO_LN_FOLD = 1 };
+ * applies to single-pass ViT blocks only (bf16, fp16, fp8, and mixed policies without DPTX_GROUP_VIT).
+ * GROUP_POLICY (dtype MIXED): do not install the default per-LAYER table of the decoder (see dptx_set_layer_precision);
+ * every layer then follows its group's bit in x3_groups (round 2's policy: 2.14x the MFMA work of single-pass instead of
+ * 1.66x, 1.5-2x smaller deviation from the fp32 forward). */
+enum { DPTX_FLAG_NO_LN_FOLD = 1, DPTX_FLAG_GROUP_POLICY = 2 };
 
 /* Fills *cfg with the reference defaults: C=3, max_batch=32, bf16, device 0, non_negative=1,
  * ws_form=0, ws_eps=1e-8. */
@@ -167,6 +170,14 @@ int dptx_forward_hw(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_d
  * are not available (its buffers were re-used). */
 int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_normal_dev, void* y_depth_dev,
                       int32_t batch, int32_t height, int32_t width, void* stream);
+
+/* dtype MIXED: per-layer precision inside the decoder (scratch.layerN_rn, refinenet*, output_conv.0 / .2).  `mfmas` = 1: the
+ * convolution multiplies the hi planes only (one MFMA per product); 3: hi/lo planes, three MFMAs.  Layers that were never set
+ * follow their group's bit in dptx_config.x3_groups.  Tensors between layers carry a lo plane exactly where a 3-MFMA consumer
+ * reads it, so every assignment is valid.  With x3_groups = 0 dptx_create installs the default table (oracle/
+ * precision_layers.py); DPTX_FLAG_GROUP_POLICY suppresses it.  May be called at any time before a forward; does not touch
+ * the packed weights.  The reference has no counterpart (it computes in fp32 throughout). */
+int dptx_set_layer_precision(dptx_handle h, const char* conv_weight_key, int32_t mfmas);
 
 /* fp8 dtype: activation scales.  Every tensor that has an e4m3 copy (the inputs of the decoder's fp8 convolutions) is
  * quantised as e4m3(x * s) with a per-tensor power-of-two scale s; e4m3 covers 2^-9 .. 448, so with s = 1 (a fresh handle)
@@ -249,6 +260,12 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
                  void* Y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                  int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
                  int32_t Wo, int32_t a_relu, int32_t act, void* stream);
+/* the same convolution with the plane switches of the MIXED dtype's per-layer policy (kernels.h GemmParams::epi2 /
+ * c_hi_only / r1_hi_only): epi2 = 1 with dtype FP16 multiplies the hi planes only but reads R and writes Y as hi/lo pairs */
+int dptx_op_conv_planes(int32_t dtype, const void* X, const void* Wt, const float* bias, const void* R, void* Y, int32_t B,
+                        int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad_t,
+                        int32_t pad_l, int32_t Ho, int32_t Wo, int32_t a_relu, int32_t act, int32_t epi2, int32_t c_hi_only,
+                        int32_t r1_hi_only, void* stream);
 /* Fused stem: x NCHW fp32 [B,3,H,W] -> y NHWC 16-bit [B,H/2,W/2,64] = conv 7x7 stride 2 with TF-SAME padding;
  * Wt [64][176] 16-bit with k = (c*7 + ky)*8 + kx (kx = 7 and k >= 168 are zero).  H % 8 == 0, W % 128 == 0. */
 int dptx_op_stem_conv(int32_t dtype, const float* x, const void* Wt, void* y, int32_t B, int32_t H, int32_t W,

@@ -328,6 +328,18 @@ struct dptx_engine {
     return (cfg.x3_groups & group) ? MODE_FP16X3 : MODE_FP16;
   }
   bool fp8() const { return cfg.dtype == DPTX_DTYPE_FP8; }
+  // Per-LAYER precision inside the decoder groups (RN / FUSION / HEAD) of the MIXED dtype: conv key (reference name without
+  // a "depth." prefix) -> 1 (one MFMA per product on the hi planes) or 3 (hi/lo planes, three MFMAs); keys that are not
+  // listed follow their group's bit in x3_groups.  The default table (dptx_create) is the cheapest assignment found by
+  // oracle/precision_layers.py that keeps the emulated deviation from the fp32 forward where the all-3-MFMA decoder has it.
+  std::unordered_map<std::string, int> layer_prec;
+  bool mixed() const { return cfg.dtype == DPTX_DTYPE_MIXED; }
+  bool layer_x3(const std::string& wkey, int group) const {
+    const std::string k = wkey.compare(0, 6, "depth.") == 0 ? wkey.substr(6) : wkey;
+    auto it = layer_prec.find(k);
+    if (it != layer_prec.end()) return it->second == 3;
+    return (cfg.x3_groups & group) != 0;
+  }
   // LayerNorm of the ViT blocks folded into the qkv / fc1 GEMMs (include/dptx.h DPTX_FLAG_NO_LN_FOLD): the packed qkv / fc1
   // weights and biases are then the folded ones, so this is fixed at dptx_create
   bool ln_fold = false;
@@ -356,10 +368,10 @@ struct dptx_engine {
   unsigned* d_amax = nullptr;    // [MAX_Q8] float bits (calibration forwards only)
   void* q8(const void* p) const { return d_arena + arena_single + ((const char*)p - d_arena) / 2; }  // e4m3 copy of an arena tensor
   // fused head tail (head.hip): single-plane head, no stage taps wanted; DPTX_HEAD_FUSED=0 keeps the three launches
-  bool head_fused() const {
+  bool head_fused(bool conv2_x3) const {
     static int env = -1;
     if (env < 0) { const char* t = getenv("DPTX_HEAD_FUSED"); env = (t && t[0] == '0') ? 0 : 1; }
-    return env == 1 && !mode_is_x3(mode_of(DPTX_GROUP_HEAD)) && !taps_on;
+    return env == 1 && !conv2_x3 && !taps_on;
   }
   size_t tok_tap_stride = 0;      // floats per token-stream snapshot
   float* d_tok_taps = nullptr;  // [13][max_batch*(max tokens)*768] fp32 copies of the token stream (taps_on)
@@ -679,17 +691,29 @@ struct Run {
       e->event_name.emplace_back(w);
     }
   }
-  void tap(const char* name, const void* p, int64_t h, int64_t w, int64_t c, bool fp32 = false) {
-    e->taps[name] = TapInfo{p, {B, h, w, c}, fp32, dt};
+  // MIXED dtype, decoder groups: which arena tensors currently have a valid lo plane (set by their producers)
+  std::unordered_map<const void*, bool> lo_valid_;
+  bool has_lo(const void* p) const {
+    auto it = lo_valid_.find(p);
+    return it != lo_valid_.end() && it->second;
   }
-  void group(int g) { dt = e->mode_of(g); }  // the launches that follow belong to layer group g
+  void mark_lo(const void* p, bool v) { lo_valid_[p] = v; }
+  int cur_group = 0;
+  void tap(const char* name, const void* p, int64_t h, int64_t w, int64_t c, bool fp32 = false) {
+    int m = dt;
+    if (e->mixed() && lo_valid_.count(p)) m = has_lo(p) ? MODE_FP16X3 : MODE_FP16;  // decoder tensors: by their own planes
+    e->taps[name] = TapInfo{p, {B, h, w, c}, fp32, m};
+  }
+  void group(int g) { dt = e->mode_of(g); cur_group = g; }  // the launches that follow belong to layer group g
 
   // NHWC convolution as implicit GEMM
   // gn_part != nullptr: the epilogue also writes the GroupNorm(32) statistics of the output (per 32-row block records,
   // kernels.h GemmParams::gn_part); the caller checked gn_fusable(Hout * Wout)
+  // out_lo (MIXED dtype, decoder groups only; -1 elsewhere): 1 = some consumer multiplies this tensor with 3 MFMAs and needs
+  // its lo plane, 0 = nobody reads it.  The layer's own arithmetic follows dptx_engine::layer_x3.
   void conv(const void* in, int Hin, int Win, int Cin, const std::string& wkey, int ksz, int stride, int pad_t, int pad_l,
             int Hout, int Wout, int Cout, void* out, const float* bias, int act, int a_relu, const void* R1 = nullptr,
-            const void* R2 = nullptr, float* gn_part = nullptr, int q = 0) {
+            const void* R2 = nullptr, float* gn_part = nullptr, int q = 0, int out_lo = -1) {
     // fp8 dtype: q = 1 / 2 also writes the e4m3 copy of the output (2: ReLU'd, for consumers that pre-activate); a conv
     // whose weight has an e4m3 copy runs on the fp8 MFMA, reading the e4m3 copy of `in` (ReLU'd by its producer)
     // (a calibration forward runs these convs on their bf16 operands: a saturated e4m3 copy upstream must not distort the
@@ -717,7 +741,20 @@ struct Run {
     }
     exec_macs += (double)p.M / B * p.N * p.K;
     cat_macs[0] += (double)p.M / B * p.N * p.K;
-    chk(launch_gemm(f8 ? MODE_FP8 : dt, p, st), wkey.c_str(), 0);
+    int mode = f8 ? MODE_FP8 : dt;
+    if (out_lo >= 0 && e->mixed()) {  // per-layer policy
+      const bool x3 = e->layer_x3(wkey, cur_group);
+      if (x3 && !has_lo(in)) {  // cannot happen with the schedule below: every producer honours its consumers' needs
+        if (err == hipSuccess) { err = hipErrorInvalidValue; where = "precision policy: a 3-MFMA layer reads a tensor without lo plane"; }
+        return;
+      }
+      const bool r1lo = R1 != nullptr && has_lo(R1), r2lo = R2 != nullptr && has_lo(R2);
+      mode = x3 ? MODE_FP16X3 : MODE_FP16;
+      p.r1_hi_only = !r1lo; p.r2_hi_only = !r2lo; p.c_hi_only = !out_lo;
+      p.epi2 = (!x3 && (out_lo || r1lo || r2lo)) ? 1 : 0;
+      mark_lo(out, out_lo != 0);
+    }
+    chk(launch_gemm(mode, p, st), wkey.c_str(), 0);
     if (slot >= 0) q8_measure(out, (size_t)p.M * p.N, q == 2, slot);
   }
 
@@ -742,10 +779,13 @@ struct Run {
 
   // RCU (blocks.py:263-286): out = conv2(relu(conv1(relu(x)))) + x (+ extra)
   // q_out (fp8 dtype): e4m3 copy of the unit's output -- 2 when its consumer pre-activates (another RCU), 1 otherwise
-  void rcu(const std::string& p, const void* x, int H, int W, void* tmp, void* out, const void* extra, int q_out) {
+  // out_lo: MIXED per-layer policy (conv()): does a consumer of the unit's output need its lo plane
+  void rcu(const std::string& p, const void* x, int H, int W, void* tmp, void* out, const void* extra, int q_out, int out_lo) {
+    const int mid_lo = e->mixed() ? (int)e->layer_x3(p + "conv2.weight", cur_group) : -1;
     conv(x, H, W, FEAT, p + "conv1.weight", 3, 1, 1, 1, H, W, FEAT, tmp, e->f(p + "conv1.bias"), /*act*/ 1, /*a_relu*/ 1, nullptr,
-         nullptr, nullptr, 1);
-    conv(tmp, H, W, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, W, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra, nullptr, q_out);
+         nullptr, nullptr, 1, mid_lo);
+    conv(tmp, H, W, FEAT, p + "conv2.weight", 3, 1, 1, 1, H, W, FEAT, out, e->f(p + "conv2.bias"), 0, 0, x, extra, nullptr, q_out,
+         e->mixed() ? out_lo : -1);
   }
 
   int forward(const void* x, void* y, void* y2);
@@ -966,6 +1006,19 @@ int Run::forward(const void* x, void* y, void* y2) {
 
   // one decoder = scratch.* of one task ("" -> scratch.*, "depth." -> depth.scratch.*); the dual-task engine runs two
   // on the same encoder outputs (S[0], S[1], L3, L4 are not modified by a decoder)
+  // MIXED dtype: the decoder groups follow the per-LAYER precision table (dptx_engine::layer_prec); a producer writes the lo
+  // plane of its output exactly when a consumer multiplies it with 3 MFMAs (or, for the path tensors, when it was computed
+  // with 3 MFMAs itself), whatever its own arithmetic is.  The encoder's outputs carry lo planes when their groups are 3-MFMA.
+  const bool mx = E->mixed();
+  if (mx) {
+    const bool enc_lo = mode_is_x3(E->mode_of(large ? DPTX_GROUP_REASSEMBLE : DPTX_GROUP_RESNET));
+    const bool re_lo = mode_is_x3(E->mode_of(DPTX_GROUP_REASSEMBLE));
+    mark_lo(A(E->S[0]), enc_lo); mark_lo(A(E->S[1]), enc_lo); mark_lo(A(E->L3), re_lo); mark_lo(A(E->L4), re_lo);
+  }
+  auto X3 = [&](const std::string& key, int grp) { return mx && E->layer_x3(key, grp); };
+  auto lo_of = [&](bool need) { return mx ? (int)need : -1; };
+  auto planes_mode = [&](const void* t) { return mx ? (has_lo(t) ? MODE_FP16X3 : MODE_FP16) : dt; };  // elementwise kernels
+
   auto decode = [&](const std::string& pre, int ch, void* yout) {
   // ---- scratch.layerN_rn (3x3, no bias) ---------------------------------------------------
   const void* rn_in[4] = {A(E->S[0]), A(E->S[1]), A(E->L3), A(E->L4)};
@@ -975,8 +1028,11 @@ int Run::forward(const void* x, void* y, void* y2) {
   const char* rn_names[4] = {"l1_rn", "l2_rn", "l3_rn", "l4_rn"};
   group(DPTX_GROUP_RN);
   for (int i = 0; i < 4; ++i) {
+    // consumer of lrn[i] as a GEMM operand: refinenet4.resConfUnit2.conv1 (i = 3), refinenet{i+1}.resConfUnit1.conv1 (else)
+    const std::string cons = pre + "scratch.refinenet" + std::to_string(i + 1) + (i == 3 ? ".resConfUnit2.conv1.weight" : ".resConfUnit1.conv1.weight");
     conv(rn_in[i], rn_h[i], rn_w[i], rn_c[i], pre + "scratch.layer" + std::to_string(i + 1) + "_rn.weight", 3, 1, 1, 1, rn_h[i],
-         rn_w[i], FEAT, A(E->lrn[i]), nullptr, 0, 0, nullptr, nullptr, nullptr, /*q: every consumer pre-activates*/ 2);
+         rn_w[i], FEAT, A(E->lrn[i]), nullptr, 0, 0, nullptr, nullptr, nullptr, /*q: every consumer pre-activates*/ 2,
+         lo_of(X3(cons, DPTX_GROUP_FUSION)));
     tap((pre + rn_names[i]).c_str(), A(E->lrn[i]), rn_h[i], rn_w[i], FEAT);
   }
 
@@ -986,6 +1042,7 @@ int Run::forward(const void* x, void* y, void* y2) {
   group(DPTX_GROUP_FUSION);
   const void* path = nullptr;
   const char* p_names[4] = {"p1", "p2", "p3", "p4"};
+  const std::string oc = pre + "scratch.output_conv.";
   for (int i = 4; i >= 1; --i) {
     const std::string p = pre + "scratch.refinenet" + std::to_string(i) + ".";
     const int h = rn_h[i - 1], w = rn_w[i - 1];
@@ -993,19 +1050,24 @@ int Run::forward(const void* x, void* y, void* y2) {
     if (i == 4) {
       sum = A(E->lrn[3]);
     } else {
-      rcu(p + "resConfUnit1.", A(E->lrn[i - 1]), h, w, A(E->tA), A(E->tB), path, 2);  // tB = path + RCU1(lrn)
+      rcu(p + "resConfUnit1.", A(E->lrn[i - 1]), h, w, A(E->tA), A(E->tB), path, 2,
+          lo_of(X3(p + "resConfUnit2.conv1.weight", DPTX_GROUP_FUSION)));  // tB = path + RCU1(lrn)
       sum = A(E->tB);
     }
-    rcu(p + "resConfUnit2.", sum, h, w, A(E->tA), A(E->tC), nullptr, 1);
-    conv(A(E->tC), h, w, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, w, FEAT, A(E->tA), E->f(p + "out_conv.bias"), 0, 0);
+    rcu(p + "resConfUnit2.", sum, h, w, A(E->tA), A(E->tC), nullptr, 1, lo_of(X3(p + "out_conv.weight", DPTX_GROUP_FUSION)));
+    // the path tensor keeps a lo plane when out_conv computed one (it is added to the next stage's sum in fp32) and when
+    // the first head conv multiplies it with 3 MFMAs
+    conv(A(E->tC), h, w, FEAT, p + "out_conv.weight", 1, 1, 0, 0, h, w, FEAT, A(E->tA), E->f(p + "out_conv.bias"), 0, 0, nullptr,
+         nullptr, nullptr, 0, lo_of(X3(p + "out_conv.weight", DPTX_GROUP_FUSION) || (i == 1 && X3(oc + "0.weight", DPTX_GROUP_HEAD))));
     // path_1 feeds the first head conv: in the fp8 dtype the up-sampling also writes its e4m3 copy
     {
       const bool up8 = E->fp8() && i == 1;
       const int slot = up8 ? q8_produce(A(E->P[0])) : -1;
-      chk(launch_upsample2x(dt, A(E->tA), A(E->P[i - 1]), B, h, w, FEAT, E->pl, st, up8 ? E->q8(A(E->P[0])) : nullptr,
-                            up8 ? E->act_scale[slot] : 1.0f),
+      chk(launch_upsample2x(planes_mode(A(E->tA)), A(E->tA), A(E->P[i - 1]), B, h, w, FEAT, E->pl, st,
+                            up8 ? E->q8(A(E->P[0])) : nullptr, up8 ? E->act_scale[slot] : 1.0f),
           "fusion.up");
       if (up8) q8_measure(A(E->P[0]), (size_t)B * 4 * h * w * FEAT, 0, slot);
+      if (mx) mark_lo(A(E->P[i - 1]), has_lo(A(E->tA)));
     }
     path = A(E->P[i - 1]);
     tap((pre + p_names[i - 1]).c_str(), path, 2 * h, 2 * w, FEAT);
@@ -1013,22 +1075,25 @@ int Run::forward(const void* x, void* y, void* y2) {
 
   // ---- head (dpt_depth.py:91-99) ----------------------------------------------------------
   group(DPTX_GROUP_HEAD);
-  const std::string oc = pre + "scratch.output_conv.";
-  conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, A(E->H0), E->f(oc + "0.bias"), 0, 0);
+  const bool conv2_x3 = mx ? X3(oc + "2.weight", DPTX_GROUP_HEAD) : mode_is_x3(dt);
+  conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, A(E->H0), E->f(oc + "0.bias"), 0, 0, nullptr, nullptr, nullptr, 0,
+       lo_of(conv2_x3));
   tap((pre + "h0").c_str(), A(E->H0), h2, w2, 128);
-  if (E->head_fused()) {
+  if (E->head_fused(conv2_x3)) {
     // x2 upsample + conv 128->32 + ReLU + conv 1x1 + ReLU in one launch (head.hip): the 37.7 MB/image up-sampled map
-    // and the 32-channel map never reach memory.  Not in bf16x3 mode, and not while stage taps are recorded ("h1").
-    chk(launch_head_tail(dt, A(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"), E->f(oc + "4.weight"), E->f(oc + "4.bias"),
-                         yout, io, B, h2, w2, ch, E->cfg.non_negative, st),
+    // and the 32-channel map never reach memory.  Not with a 3-MFMA conv2, and not while stage taps are recorded ("h1").
+    chk(launch_head_tail(mx ? MODE_FP16 : dt, A(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"), E->f(oc + "4.weight"),
+                         E->f(oc + "4.bias"), yout, io, B, h2, w2, ch, E->cfg.non_negative, st),
         "head.tail", 0);
     exec_macs += (double)Hi * Wi * 32 * 1152;
     cat_macs[0] += (double)Hi * Wi * 32 * (1152 + ch);
   } else {
-    chk(launch_upsample2x(dt, A(E->H0), A(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
-    conv(A(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, A(E->H1), E->f(oc + "2.bias"), 1, 0);
+    chk(launch_upsample2x(planes_mode(A(E->H0)), A(E->H0), A(E->H0U), B, h2, w2, 128, E->pl, st), "head.up");
+    if (mx) mark_lo(A(E->H0U), has_lo(A(E->H0)));
+    conv(A(E->H0U), Hi, Wi, 128, oc + "2.weight", 3, 1, 1, 1, Hi, Wi, 32, A(E->H1), E->f(oc + "2.bias"), 1, 0, nullptr, nullptr,
+         nullptr, 0, lo_of(conv2_x3));
     tap((pre + "h1").c_str(), A(E->H1), Hi, Wi, 32);
-    chk(launch_head_out(dt, A(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, io, B, Hi * Wi, ch,
+    chk(launch_head_out(planes_mode(A(E->H1)), A(E->H1), E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, io, B, Hi * Wi, ch,
                         E->cfg.non_negative, E->pl, st),
         "head.out");
   }
@@ -1088,7 +1153,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_FP8 || (cfg->ws_form != 0 && cfg->ws_form != 1) ||
-      (cfg->flags & ~DPTX_FLAG_NO_LN_FOLD) || cfg->reserved != 0)
+      (cfg->flags & ~(DPTX_FLAG_NO_LN_FOLD | DPTX_FLAG_GROUP_POLICY)) || cfg->reserved != 0)
     return DPTX_E_INVALID;
   int x3_groups = 0;
   if (cfg->dtype == DPTX_DTYPE_MIXED) {
@@ -1108,6 +1173,18 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   e->backbone = cfg->backbone;
   if (e->backbone == DPTX_BACKBONE_VITL16_384) { e->dv = 1024; e->dm = 4096; e->nh = 16; e->depth = 24; }
   e->max_h = max_h;
+  if (cfg->dtype == DPTX_DTYPE_MIXED && cfg->x3_groups == 0 && !(cfg->flags & DPTX_FLAG_GROUP_POLICY)) {
+    // default per-layer table of the decoder (oracle/precision_layers.py: per-layer sensitivities on both synthetic weight
+    // families; "policy A" of profiles/r03_precision_layers.md): these nine 3x3 convolutions -- 30.6 of the decoder's 57.7
+    // GMAC -- run one MFMA per product, because their operand rounding moves the output 10x less per MAC than the 1x1
+    // out_convs, the deep (low-resolution) fusion stages and the head do
+    for (const char* k : {"scratch.layer1_rn.weight",
+                          "scratch.refinenet1.resConfUnit1.conv1.weight", "scratch.refinenet1.resConfUnit1.conv2.weight",
+                          "scratch.refinenet1.resConfUnit2.conv1.weight", "scratch.refinenet1.resConfUnit2.conv2.weight",
+                          "scratch.refinenet2.resConfUnit1.conv1.weight", "scratch.refinenet2.resConfUnit1.conv2.weight",
+                          "scratch.refinenet3.resConfUnit1.conv1.weight", "scratch.refinenet3.resConfUnit1.conv2.weight"})
+      e->layer_prec[k] = 1;
+  }
   {
     // fused schedules (include/dptx.h DPTX_FLAG_*; the environment variables are for A/B runs of one binary)
     const char* t = getenv("DPTX_LN_FOLD");
@@ -1348,6 +1425,18 @@ int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y
   return run_forward(h, x_dev, x_dtype, y_normal_dev, y_depth_dev, batch, height, width, (hipStream_t)stream);
 }
 
+int dptx_set_layer_precision(dptx_handle h, const char* conv_weight_key, int32_t mfmas) {
+  if (!h || !conv_weight_key || (mfmas != 1 && mfmas != 3)) return DPTX_E_INVALID;
+  if (!h->mixed()) return h->fail(DPTX_E_INVALID, "per-layer precision applies to dtype = DPTX_DTYPE_MIXED");
+  std::string k = conv_weight_key;
+  if (k.compare(0, 6, "depth.") == 0) k = k.substr(6);
+  const bool decoder = k.compare(0, 8, "scratch.") == 0 && k.size() > 7 && k.compare(k.size() - 7, 7, ".weight") == 0 &&
+                       k.find("output_conv.4") == std::string::npos && h->spec_index.count(k) && h->spec[h->spec_index[k]].role == R_CONV;
+  if (!decoder) return h->fail(DPTX_E_KEY, std::string("not a decoder convolution (scratch.*): ") + conv_weight_key);
+  h->layer_prec[k] = mfmas;
+  return DPTX_OK;
+}
+
 int dptx_calibrate_fp8(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, void* y2_dev, int32_t batch, int32_t height,
                        int32_t width, void* stream) {
   if (!h || !x_dev || !y_dev) return DPTX_E_INVALID;
@@ -1525,6 +1614,22 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
   p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act; p.a_relu = a_relu; p.planes = g_op_planes;
   p.k_tap_fast = (ksize == 3 && Cin >= 512) ? 1 : 0;
+  return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+int dptx_op_conv_planes(int32_t dtype, const void* X, const void* Wt, const float* bias, const void* R, void* Y, int32_t B, int32_t H,
+                        int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
+                        int32_t Wo, int32_t a_relu, int32_t act, int32_t epi2, int32_t c_hi_only, int32_t r1_hi_only, void* stream) {
+  GemmParams p{};
+  p.A = X; p.W = Wt; p.C = Y; p.bias = bias; p.R1 = R;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = ksize * ksize * Cin; p.ldw = p.K;
+  p.a_rpi = Ho * Wo; p.Wout = Wo; p.Hin = H; p.Win = W; p.Cin = Cin; p.a_pix_stride = Cin;
+  p.a_img_stride = (long long)H * W * Cin;
+  p.a_bytes = (long long)B * H * W * Cin * 2;
+  p.ksz = ksize; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.c_rpi = 0x7fffffff; p.ldc = Cout; p.act = act; p.a_relu = a_relu; p.planes = g_op_planes;
+  p.k_tap_fast = (ksize == 3 && Cin >= 512) ? 1 : 0;
+  p.epi2 = epi2; p.c_hi_only = c_hi_only; p.r1_hi_only = r1_hi_only;
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 

@@ -41,8 +41,8 @@ hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
 #ifdef DPTX_EXPERIMENTS
   if (halo_shape(p)) p.k_tap_fast = 1;  // one k order for these shapes, whichever kernel runs them (all modes)
 #endif
-  if (mode == MODE_BF16) return launch_gemm_16(DT_BF16, p, stream);
-  if (mode == MODE_FP16) return launch_gemm_16(DT_FP16, p, stream);
+  if (mode == MODE_BF16) return p.epi2 ? hipErrorInvalidValue : launch_gemm_16(DT_BF16, p, stream);
+  if (mode == MODE_FP16) return p.epi2 ? launch_gemm_fp16e(p, stream) : launch_gemm_16(DT_FP16, p, stream);
   if (mode == MODE_BF16X3) return launch_gemm_x3(DT_BF16, p, stream);
   if (mode == MODE_FP16X3) return launch_gemm_x3(DT_FP16, p, stream);
   return hipErrorInvalidValue;

@@ -321,7 +321,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             ra[it][1] = src[1];
           } else {
             ra[it][0] = *(const u32x4_t*)((const uint16_t*)p.R1 + coff[it]);
-            if (PL == 2) ra[it][1] = *(const u32x4_t*)((const uint16_t*)p.R1 + p.planes.act + coff[it]);
+            if (PL == 2) {
+              ra[it][1] = u32x4_t{0u, 0u, 0u, 0u};
+              if (!p.r1_hi_only) ra[it][1] = *(const u32x4_t*)((const uint16_t*)p.R1 + p.planes.act + coff[it]);
+            }
           }
         }
         if (r2) {
@@ -332,7 +335,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             rb[it][1] = src[1];
           } else {
             rb[it][0] = *(const u32x4_t*)((const uint16_t*)p.R2 + off);
-            if (PL == 2) rb[it][1] = *(const u32x4_t*)((const uint16_t*)p.R2 + p.planes.act + off);
+            if (PL == 2) {
+              rb[it][1] = u32x4_t{0u, 0u, 0u, 0u};
+              if (!p.r2_hi_only) rb[it][1] = *(const u32x4_t*)((const uint16_t*)p.R2 + p.planes.act + off);
+            }
           }
         }
         if (bpi) {
@@ -443,6 +449,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
               float* cp = (float*)p.C + coff[it];
               *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
               *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else if (PL == 2 && p.c_hi_only) {
+              store8f<DT, 1>((uint16_t*)p.C + coff[it], 0, v);
             } else {
               store8f<DT, PL>((uint16_t*)p.C + coff[it], p.planes.act, v);
             }
@@ -478,7 +486,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
 // ------------------------------------------------------------------- direct-to-LDS kernel
 constexpr unsigned OOB = 0x80000000u;  // >= any buffer size we bind (a_bytes < 2^31): reads as zero
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A, int PL>
+// PLE: planes of the EPILOGUE (residual reads, C stores).  PLE == PL by default; PLE == 2 on a single-plane (PL == 1)
+// kernel is the per-layer precision policy's "single-pass compute, two-plane tensors": a layer that multiplies hi planes
+// only may still read the lo planes of its residuals and write a lo plane for a 3-MFMA consumer
+// (GemmParams::c_hi_only / r1_hi_only / r2_hi_only switch the individual planes off).
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A, int PL, int PLE = PL>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_glds_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer/LDS-DMA builtins exist only in the device pass
   constexpr int NT = 64 * WAVES_M * WAVES_N;  // 256 threads (2 blocks/CU), or 512 for the 256x256 tile (1 block/CU)
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
 #undef DPTX_STAMP
 #undef DPTX_ISSUE_TILE
   __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
-  epilogue<DTS, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+  epilogue<DTS, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
 }
 
@@ -699,7 +711,7 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 // (Round 2 measured seven variants of this schedule -- third LDS buffer, all DMA on one group, one barrier per k-tile with
 // overlapping MFMA slots, s_setprio, the guide's 8-phase structure, a 256x128 three-stage tile, an LDS-resident conv halo
 // -- all <= 0: profiles/r02_experiments.md; the three that are kernels of their own live in experiments/.)
-template <int DT, bool RELU_A>
+template <int DT, bool RELU_A, int PLE = 1>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #undef DPTX_PP_NEXT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  epilogue<DT, BM, BN, TM, TN, PL, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+  epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
 }
 
@@ -1068,7 +1080,7 @@ static void choose_xcd_grid(const GemmParams& p, int tiles_m, int tiles_n, int& 
 #include "experiments/gemm_experiments_dispatch.h"
 #endif
 
-template <int DT, int PL, int BM, int BN, int WM_, int WN_>
+template <int DT, int PL, int BM, int BN, int WM_, int WN_, int PLE = PL>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
   GemmParams q = p;
@@ -1090,30 +1102,30 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
         set_smem_attr(k, smem);
         hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
       };
-      if (p.a_relu) go(gemm_pp_kernel<DT, true>);
-      else go(gemm_pp_kernel<DT, false>);
+      if (p.a_relu) go(gemm_pp_kernel<DT, true, PLE>);
+      else go(gemm_pp_kernel<DT, false, PLE>);
       return hipGetLastError();
     }
   }
   if constexpr (DT == DT_FP8) {  // fp8 operands: direct-to-LDS path only, pre-activation is the producer's job
     if (!glds_ok || p.a_relu) return hipErrorInvalidValue;
-    auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
+    auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL, PLE>;
     set_smem_attr(k, smem);
     hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     return hipGetLastError();
   } else
   if (glds_ok && (PL == 2 || gemm_variant() != 1)) {
     if (p.a_relu) {
-      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL>;
+      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL, PLE>;
       set_smem_attr(k, smem);
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     } else {
-      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL>;
+      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL, PLE>;
       set_smem_attr(k, smem);
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     }
-  } else if constexpr (WM_ * WN_ != 4) {
-    return hipErrorInvalidValue;  // the 8-wave tile exists only on the direct-to-LDS path
+  } else if constexpr (WM_ * WN_ != 4 || PLE != PL) {
+    return hipErrorInvalidValue;  // the 8-wave tile and the two-plane epilogue exist only on the direct-to-LDS path
   } else if constexpr (PL == 1) {
     constexpr size_t smem1 = gemm_smem_bytes<BM, BN, 1>();
     if (p.a_fp32) {
@@ -1134,16 +1146,16 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int DT, int PL>
+template <int DT, int PL, int PLE = PL>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
   const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
   static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (tools/gemm_bench.py)
   if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
   {
-    if (forced == 128128 && p.N % 128 == 0) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
-    if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
-    if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
+    if (forced == 128128 && p.N % 128 == 0) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE>(p, stream);
+    if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE>(p, stream);
+    if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE>(p, stream);
   }
 #ifdef DPTX_EXPERIMENTS
   {
@@ -1162,23 +1174,23 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
       const long long t256 = m256 * (p.N / 256), r256 = (t256 + 255) / 256;
       const long long t128 = m128 * (p.N / 128), r128 = (t128 + 511) / 512;
       const double fill256 = (double)t256 / (double)(r256 * 256), fill128 = (double)t128 / (double)(r128 * 512);
-      if (t256 >= 200 && fill256 * 1.25 >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4>(p, stream);
+      if (t256 >= 200 && fill256 * 1.25 >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4, PLE>(p, stream);
     }
   }
   if constexpr (PL == 2) {
     // 3-MFMA modes are one block per CU (two planes of two stages = 128 KB of LDS); eight waves (2 x 4, wave tile
     // 64 x 32) instead of four put two waves on every SIMD, so that one's fragment reads overlap the other's MFMAs:
     // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md)
-    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200) return launch_cfg<DT, PL, 128, 128, 2, 4>(p, stream);
+    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200) return launch_cfg<DT, PL, 128, 128, 2, 4, PLE>(p, stream);
   }
   // (row_stats -- the producer side of the LayerNorm fold -- reduces 128-column blocks inside a tile: never narrower tiles)
   // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
   // 128x64 by 2..10 %, whose second round is nearly empty
-  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2>(p, stream);
-  if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1>(p, stream);
-  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 256, 64, 4, 1>(p, stream);
-  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 128, 64, 2, 2>(p, stream);
-  if (p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2>(p, stream);
+  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE>(p, stream);
+  if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1, PLE>(p, stream);
+  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 256, 64, 4, 1, PLE>(p, stream);
+  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE>(p, stream);
+  if (p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE>(p, stream);
   return hipErrorInvalidValue;
 }
 
@@ -1186,6 +1198,7 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
 // per-translation-unit entry points (launch_gemm dispatches to them)
 hipError_t launch_gemm_16(int dt, const GemmParams& p, hipStream_t stream);   // gemm.hip:     DT_BF16 one plane (fp16: next line)
 hipError_t launch_gemm_fp16(const GemmParams& p, hipStream_t stream);         // gemm_fp16.hip: DT_FP16, one plane
+hipError_t launch_gemm_fp16e(const GemmParams& p, hipStream_t stream);        // gemm_fp16e.hip: DT_FP16, one plane, two-plane epilogue
 hipError_t launch_gemm_x3(int dt, const GemmParams& p, hipStream_t stream);   // gemm_x3.hip:  DT_BF16 / DT_FP16, hi/lo planes
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream);          // gemm_fp8.hip: e4m3
 

@@ -39,6 +39,10 @@ struct GemmParams {
   int a_fp32;        // A elements are fp32 (converted while staging)
   int c_fp32, r1_fp32, r2_fp32;
   Planes planes;  // hi->lo plane distances (bf16x3 mode only)
+  // per-layer precision policy (dtype "mixed"): epi2 = 1 runs the two-plane epilogue on a single-pass (one MFMA per product)
+  // fp16 kernel -- residuals are read with their lo planes and C is written as a hi/lo pair; *_hi_only (two-plane epilogues,
+  // also of the 3-MFMA kernels) switch off the lo plane of C / R1 / R2 individually
+  int epi2, c_hi_only, r1_hi_only, r2_hi_only;
   int xcd_m, xcd_n;  // XCD grid of the tile partition (filled in by launch_gemm)
   int k_tap_fast;    // visit the k-tiles taps-fastest inside a 64-channel block (3x3 convs with Cin >= 512: +12..17 %)
   // GroupNorm(32) statistics of the output from the epilogue (null: none): partial[img][gn_blocks][32] float2 records

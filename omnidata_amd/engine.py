@@ -54,6 +54,7 @@ ABI = [
     ("dptx_forward", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
     ("dptx_forward_hw", C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_forward_dual", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("dptx_set_layer_precision", C.c_int, [_vp, C.c_char_p, _i32]),
     ("dptx_calibrate_fp8", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_fp8_get_calibration", C.c_int, [_vp, _f32p, _f32p, _i32]),
     ("dptx_fp8_set_calibration", C.c_int, [_vp, _f32p, _i32]),
@@ -72,6 +73,7 @@ ABI = [
     ("dptx_op_set_planes", C.c_int, [C.c_int64, C.c_int64]),
     ("dptx_op_gemm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     ("dptx_op_conv", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [_vp]),
+    ("dptx_op_conv_planes", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 16 + [_vp]),
     ("dptx_op_stem_conv", C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_op_attention", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_op_layernorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
@@ -147,7 +149,7 @@ class Engine:
         cfg.streams = int(streams)
         cfg.x3_groups = groups_mask(x3_groups)  # dtype "mixed": groups that run 3 MFMAs per product (0 = all but the ViT blocks)
         cfg.backbone = BACKBONE_IDS[backbone]
-        cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold)
+        cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold, 2: group-level precision policy only)
         self.cfg = cfg
         self.fp8_calibrated = False
         self.dtype = dtype
@@ -276,6 +278,10 @@ class Engine:
         self._check(self.lib.dptx_forward_dual(self.h, x.data_ptr(), IO_DTYPES[x.dtype], out_normal.data_ptr(), out_depth.data_ptr(), B, H, W,
                                                _stream(x.device)), "forward_dual")
         return out_normal, out_depth
+
+    def set_layer_precision(self, conv_weight_key: str, mfmas: int):
+        """dtype 'mixed': run one decoder convolution with 1 or 3 MFMAs per product (include/dptx.h)."""
+        self._check(self.lib.dptx_set_layer_precision(self.h, conv_weight_key.encode(), int(mfmas)), "set_layer_precision")
 
     # ---- fp8 dtype: per-tensor activation scales (include/dptx.h dptx_calibrate_fp8)
     def calibrate_fp8(self, x: torch.Tensor):

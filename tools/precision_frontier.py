@@ -20,9 +20,13 @@ from omnidata_amd.engine import Engine  # noqa: E402
 from omnidata_amd.weights import random_state_dict, synthetic_input  # noqa: E402
 from oracle.dpt_oracle import dpt_forward, mean_angular_error_deg, oracle_threads  # noqa: E402
 
-MODES = [("bf16", 0), ("fp16", 0), ("mixed", "resnet"), ("mixed", "resnet+embed"),
-         ("mixed", "resnet+embed+reassemble+rn+fusion"), ("mixed", 0), ("mixed", "resnet+embed+vit+reassemble+rn+fusion"),
-         ("fp16x3", 0), ("bf16x3", 0)]
+# (dtype, x3 groups, flags, per-layer overrides {conv key: mfmas})
+HEAD0 = "scratch.output_conv.0.weight"
+MODES = [("bf16", 0, 0, {}), ("fp16", 0, 0, {}), ("mixed", "resnet", 0, {}), ("mixed", "resnet+embed+reassemble+rn+fusion", 0, {}),
+         ("mixed", 0, 0, {HEAD0: 1}),   # default per-layer table with the first head conv single-pass too ("policy C")
+         ("mixed", 0, 0, {}),           # default: per-layer table of the decoder ("policy A")
+         ("mixed", 0, 2, {}),           # DPTX_FLAG_GROUP_POLICY: round 2's default (every group but the ViT blocks)
+         ("fp16x3", 0, 0, {}), ("bf16x3", 0, 0, {})]
 
 
 def main():
@@ -34,17 +38,22 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     oracle_threads()
-    lines = ["| weights | dtype | x3 groups | max abs d | rms d | mean angular err (deg) | img/s (B=%d) | meets 1e-3 |" % args.batch,
-             "|---|---|---|---|---|---|---|---|"]
+    lines = ["| weights | dtype | 3-MFMA layers | max abs d (1 img) | max abs d (4 img) | rms d | mean angular err (deg) | img/s (B=%d) | meets 1e-3 |" % args.batch,
+             "|---|---|---|---|---|---|---|---|---|"]
     xb = synthetic_input(1000, args.batch, "normal").to(dev)
     yb = torch.empty(args.batch, 3, 384, 384, device=dev)
     for fam in args.families:
         sd = random_state_dict(0, 3, family=fam)
         x1 = synthetic_input(0, 1, "normal")
         ref = dpt_forward(sd, x1)
-        for dtype, groups in MODES:
-            eng = Engine(num_channels=3, max_batch=args.batch, dtype=dtype, device_id=0, x3_groups=groups)
+        x4 = synthetic_input(1000, 4, "normal")
+        ref4 = dpt_forward(sd, x4)
+        for dtype, groups, flags, over in MODES:
+            eng = Engine(num_channels=3, max_batch=args.batch, dtype=dtype, device_id=0, x3_groups=groups, flags=flags)
             eng.load_state_dict(sd)
+            for k, m in over.items():
+                eng.set_layer_precision(k, m)
+            d4 = (eng.forward(x4.to(dev)).cpu() - ref4).abs().max().item()
             y = eng.forward(x1.to(dev)).cpu()
             d = (y - ref).abs()
             ang = mean_angular_error_deg(y.clamp(0, 1), ref.clamp(0, 1))
@@ -57,8 +66,10 @@ def main():
             torch.cuda.synchronize()
             ips = args.batch * args.steps / (time.perf_counter() - t0)
             g = groups if groups else ("all but vit" if dtype == "mixed" else "-")
-            line = (f"| {fam} | {dtype} | {g} | {d.max():.2e} | {d.pow(2).mean().sqrt():.2e} | {ang:.3f} | {ips:.0f} | "
-                    f"{'yes' if d.max() < 1e-3 else 'no'} |")
+            if dtype == "mixed" and not groups:
+                g = "all but vit, group level (r2)" if flags else ("per-layer table" + (" + head.0 single" if over else ""))
+            line = (f"| {fam} | {dtype} | {g} | {d.max():.2e} | {d4:.2e} | {d.pow(2).mean().sqrt():.2e} | {ang:.3f} | {ips:.0f} | "
+                    f"{'yes' if max(d.max().item(), d4) < 1e-3 else 'no'} |")
             print(line, flush=True)
             lines.append(line)
             eng.close()
