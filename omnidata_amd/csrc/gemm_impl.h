@@ -259,6 +259,29 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
     }
   }
   const bool remap = p.c_rpi != 0x7fffffff;  // token-row remap (patch-embed, readout); everything else skips the division
+  // LayerNorm fold, consumer side: (mu, rstd) of the tile's BM rows, combined ONCE per row from its (sum, sum of squares)
+  // records (row stride 8 records, ln_nblk = 6 or 8 valid) into an LDS table behind the C tile -- every row is needed by
+  // the 32 (16) threads that own its columns, in every n-tile: per-thread combining cost 64 sixteen-byte loads per thread
+  // and tile (+11..14 us per qkv / fc1 launch, profiles/r03_experiments.md).  The table is written before the first
+  // __syncthreads() of the slab loop and read after it.
+  float2* lnrow = (float2*)(smem + (size_t)CT_ROWS * CT_PITCH * 4);
+  if (p.ln_stats != nullptr) {
+    const bool all8 = p.ln_nblk == 8;
+    for (int r = tid; r < BM; r += NT) {
+      int R = r;
+      if (row_pitch) R = (R >> 5) * row_pitch + (R & 31);
+      int m = m0 + R;
+      m = m < p.M ? m : m0;
+      const float4* st = (const float4*)(p.ln_stats + (long long)m * 16);
+      const float4 r0 = st[0], r1_ = st[1], r2_ = st[2], r3_ = st[3];
+      const float sm = (r0.x + r0.z) + (r1_.x + r1_.z) + ((r2_.x + r2_.z) + (all8 ? r3_.x + r3_.z : 0.f));
+      const float sq = (r0.y + r0.w) + (r1_.y + r1_.w) + ((r2_.y + r2_.w) + (all8 ? r3_.y + r3_.w : 0.f));
+      const float mu = sm * p.ln_inv_dim;
+      // E[x^2] - mu^2 in double: the subtraction is where the bits would go
+      const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
+      lnrow[r] = make_float2(mu, __builtin_amdgcn_rsqf(fmaxf((float)var, 0.f) + p.ln_eps));
+    }
+  }
   // rows per load group: 4 (96 registers of loads in flight at most); 2 for the slab epilogue, whose 128 accumulator
   // registers stay live across the slabs
   constexpr int GR = SLABS > 1 ? 2 : (ITER < 4 ? ITER : 4);
@@ -278,7 +301,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       ln_c[0] = c0.x; ln_c[1] = c0.y; ln_c[2] = c0.z; ln_c[3] = c0.w;
       ln_c[4] = c1.x; ln_c[5] = c1.y; ln_c[6] = c1.z; ln_c[7] = c1.w;
     }
-    float4 ln_rec[GR][4];
+    int ln_R[GR];  // tile row of the thread's row `it` (index into the LDS table of (mu, rstd))
     const bool r1 = R1M < 0 ? p.R1 != nullptr : R1M > 0, r2 = R2M < 0 ? p.R2 != nullptr : R2M > 0;
     const bool r1f = R1M < 0 ? p.r1_fp32 != 0 : R1M == 2, r2f = R2M < 0 ? p.r2_fp32 != 0 : R2M == 2;
     const bool bpi = BPI < 0 ? p.bias_per_img != 0 : BPI > 0;
@@ -294,6 +317,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         int R = SLABS == 1 ? row
                 : ILV      ? (s >> 1) * 128 + (row >> 5) * 64 + (s & 1) * 32 + (row & 31)
                            : (row >> 5) * (TM * 32) + s * 32 + (row & 31);
+        if (LNF) ln_R[it] = R;  // tile row: index into the LDS table of (mu, rstd)
         if (row_pitch) R = (R >> 5) * row_pitch + (R & 31);
         int m = m0 + R;
         ok[it] = m < p.M;
@@ -306,14 +330,6 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
         coff[it] = crow * p.ldc + n;
         crow_[it] = (int)crow;
-        if (LNF) {
-          // the (sum, sum of squares) records of GEMM row m (row stride 8 records, ln_nblk = 6 or 8 of them valid), read as float4 pairs (every thread of a row
-          // reads the same addresses: broadcast).  Only the loads are issued here; they are combined where the row is
-          // written (a wait in this place would serialise a memory latency per row group)
-          const float4* st = (const float4*)(p.ln_stats + (long long)m * 16);  // row stride 8 records; ln_nblk (6 or 8) are valid
-#pragma unroll
-          for (int j = 0; j < 4; ++j) ln_rec[it][j] = st[j];
-        }
         if (r1) {
           if (r1f) {
             const u32x4_t* src = (const u32x4_t*)((const float*)p.R1 + coff[it]);
@@ -386,17 +402,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             for (int e = 0; e < 8; ++e) v[e] *= osc[e];
           }
           if (LNF) {
-            const bool all8 = p.ln_nblk == 8;  // D = 1024; D = 768 has 6 records (the last float4 of the row is not written)
-            const float sm = (ln_rec[it][0].x + ln_rec[it][0].z) + (ln_rec[it][1].x + ln_rec[it][1].z) +
-                             ((ln_rec[it][2].x + ln_rec[it][2].z) + (all8 ? ln_rec[it][3].x + ln_rec[it][3].z : 0.f));
-            const float sq = (ln_rec[it][0].y + ln_rec[it][0].w) + (ln_rec[it][1].y + ln_rec[it][1].w) +
-                             ((ln_rec[it][2].y + ln_rec[it][2].w) + (all8 ? ln_rec[it][3].y + ln_rec[it][3].w : 0.f));
-            const float mu = sm * p.ln_inv_dim;
-            // E[x^2] - mu^2 in double: the subtraction is where the bits would go
-            const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
-            const float rs = __builtin_amdgcn_rsqf(fmaxf((float)var, 0.f) + p.ln_eps);
+            const float2 ms = lnrow[ln_R[it]];  // (mu, rstd) of this row: one LDS broadcast read per 32 threads
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaf(-mu, ln_c[e], v[e]) * rs;
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(-ms.x, ln_c[e], v[e]) * ms.y;
           }
           if (bpi) {
 #pragma unroll
@@ -1028,7 +1036,8 @@ template <int BM, int BN, int PL>
 constexpr size_t gemm_smem_bytes() {
   constexpr size_t stage = 2 * (size_t)PL * (BM + BN) * 128;
   constexpr size_t ct_full = (size_t)BM * (BN + 4) * 4;
-  constexpr size_t ct = ct_full > 160 * 1024 ? (size_t)64 * (BN + 4) * 4 : ct_full;  // slab epilogue (2 wave rows x 32)
+  constexpr size_t ct = (ct_full > 160 * 1024 ? (size_t)64 * (BN + 4) * 4 : ct_full)  // slab epilogue (2 wave rows x 32)
+                        + (size_t)BM * 8;  // + the (mu, rstd) row table of the LayerNorm fold
   return stage > ct ? stage : ct;
 }
 

@@ -32,17 +32,35 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const void* __restric
   const int ox0 = (blockIdx.x % tiles_x) * 64, oy0 = (blockIdx.x / tiles_x) * 4, b = blockIdx.y;
   const int iy0 = 2 * oy0 - pad_t, ix0 = 2 * ox0 - pad_l;
 
-  // ---- input patch -> LDS (zero outside the image and in the pitch padding)
+  // ---- input patch -> LDS (zero outside the image and in the pitch padding).  A wave owns one (channel, row) line of the
+  // patch per pass and moves it as column PAIRS: the patch starts at an even column (ix0 = 128 k - pad_l, pad_l = 2) and W is
+  // even, so a pair is either inside the image or outside it -- one 8-byte (fp32) / 4-byte (16-bit) load and one ds_write_b32
+  // per pair instead of two scalar loads, two conversions and four integer divisions per element
   const long long xb = (long long)b * 3 * H * W;  // element offset of image b (x is fp32, bf16 or fp16: `io`)
-  for (int i = tid; i < ST_PATCH; i += 256) {
-    const int col = i % ST_PITCH, rc = i / ST_PITCH;
-    const int r = rc % ST_ROWS, c = rc / ST_ROWS;
-    const int iy = iy0 + r, ix = ix0 + col;
-    float v = 0.f;
-    if (col < 134 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = io_load(x, xb + ((long long)c * H + iy) * W + ix, io);
-    const uint16_t hi = T16<DT>::fromf(v);
-    patch[i] = hi;
-    if (PL == 2) patch[ST_PATCH + i] = T16<DT>::fromf(v - T16<DT>::tof(hi));
+  for (int rc = wave; rc < 3 * ST_ROWS; rc += 4) {
+    const int c = rc / ST_ROWS, r = rc - c * ST_ROWS;
+    const int iy = iy0 + r;
+    const bool rowok = (unsigned)iy < (unsigned)H;
+    const long long rowoff = xb + ((long long)c * H + iy) * W;
+    for (int cp = lane; cp < ST_PITCH / 2; cp += 64) {
+      const int col = 2 * cp, ix = ix0 + col;
+      float v0 = 0.f, v1 = 0.f;
+      if (rowok && col < 134 && (unsigned)ix < (unsigned)W) {
+        if (io == IO_FP32) {
+          const float2 t = *(const float2*)((const float*)x + rowoff + ix);
+          v0 = t.x; v1 = t.y;
+        } else {
+          const uint32_t t = *(const uint32_t*)((const uint16_t*)x + rowoff + ix);
+          v0 = io == IO_BF16 ? T16<DT_BF16>::tof((uint16_t)(t & 0xffffu)) : T16<DT_FP16>::tof((uint16_t)(t & 0xffffu));
+          v1 = io == IO_BF16 ? T16<DT_BF16>::tof((uint16_t)(t >> 16)) : T16<DT_FP16>::tof((uint16_t)(t >> 16));
+        }
+      }
+      const uint32_t hi = T16<DT>::pack2(v0, v1);
+      *(uint32_t*)(patch + rc * ST_PITCH + col) = hi;
+      if (PL == 2)
+        *(uint32_t*)(patch + ST_PATCH + rc * ST_PITCH + col) =
+            T16<DT>::pack2(v0 - T16<DT>::tof((uint16_t)(hi & 0xffffu)), v1 - T16<DT>::tof((uint16_t)(hi >> 16)));
+    }
   }
   __syncthreads();
 

@@ -233,7 +233,7 @@ def test_two_stream_split_is_bit_identical():
         assert torch.equal(y2, y[:5])
         outs.append(y)
         n, _, _ = eng.info()
-        assert (n > 400) == (streams == 2)
+        assert (n > 300) == (streams == 2)   # 2 x 199 launches on two streams, 199 on one
         eng.close()
     assert torch.equal(outs[0], outs[1])
 

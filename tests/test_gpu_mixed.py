@@ -142,7 +142,7 @@ def test_mixed_stage_taps():
         got, want = eng.tap(n), otaps[n]
         rel[n] = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
         print(f"    tap {n:6s} rms-rel err {rel[n]:.3e}")
-    assert max(rel[n] for n in ("stem", "s0", "s1", "s2", "tok0", "l4_rn")) < 5e-5   # 3-MFMA layers
+    assert max(rel[n] for n in ("stem", "s0", "s1", "s2", "tok0")) < 5e-5   # 3-MFMA layers upstream of the ViT blocks
     assert rel["l1_rn"] < 5e-4   # layer1_rn is single-pass in the default per-layer table: one fp16 operand rounding
     assert max(rel.values()) < 2e-3
 
