@@ -101,7 +101,8 @@ typedef struct dptx_config {
  * 1.66x, 1.5-2x smaller deviation from the fp32 forward). */
 enum { DPTX_FLAG_NO_LN_FOLD = 1, DPTX_FLAG_GROUP_POLICY = 2 };
 
-/* Fills *cfg with the reference defaults: C=3, max_batch=32, bf16, device 0, non_negative=1,
+/* Fills *cfg with the reference defaults: C=3, max_batch=32, dtype MIXED (the mode that matches the reference's fp32
+ * forward within 1e-3; DPTX_DTYPE_BF16 is the ~1.6x faster throughput mode that does not), device 0, non_negative=1,
  * ws_form=0, ws_eps=1e-8. */
 void dptx_default_config(dptx_config* cfg);
 

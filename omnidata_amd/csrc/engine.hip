@@ -1132,7 +1132,7 @@ void dptx_default_config(dptx_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->num_channels = 3;
   cfg->max_batch = 32;
-  cfg->dtype = DPTX_DTYPE_BF16;
+  cfg->dtype = DPTX_DTYPE_MIXED;  // the mode that matches the reference's fp32 forward within 1e-3; BF16 is the throughput mode
   cfg->device_id = 0;
   cfg->non_negative = 1;
   cfg->ws_form = 0;

@@ -134,7 +134,7 @@ def _check_out(out: torch.Tensor, shape, device, dtype=torch.float32):
 class Engine:
     """One dptx handle: packed weights + activation arena on one GPU (or host-only packing)."""
 
-    def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "bf16",
+    def __init__(self, num_channels: int = 3, max_batch: int = 32, dtype: str = "mixed",
                  device_id: Optional[int] = 0, non_negative: bool = True, ws_form: int = 0, ws_eps: float = 1e-8,
                  max_hw: Tuple[int, int] = (384, 384), dual: bool = False, streams: int = 0, x3_groups=0,
                  backbone: str = "vitb_rn50_384", flags: int = 0):

@@ -144,8 +144,8 @@ def test_dual_task_spec_and_packing():
     assert all(back[k] is sd[k] for k in sd)
     assert compose_dual_state_dict(random_state_dict(0, 3), random_state_dict(1, 1), backbone="depth")[
         "pretrained.model.cls_token"].equal(random_state_dict(1, 1)["pretrained.model.cls_token"])
-    dual = Engine(num_channels=3, max_batch=1, device_id=None, dual=True)
-    one = Engine(num_channels=3, max_batch=1, device_id=None)
+    dual = Engine(num_channels=3, max_batch=1, device_id=None, dual=True, dtype="bf16")   # one plane: the prefix property below
+    one = Engine(num_channels=3, max_batch=1, device_id=None, dtype="bf16")
     dual.load_state_dict(sd)
     assert dual.packed_bytes > one.packed_bytes
     blob = dual.export_packed_host()
