@@ -38,6 +38,12 @@ def _newer(dst: str, srcs) -> bool:
     return all(os.path.getmtime(s) <= t for s in srcs)
 
 
+def built_hash(suffix: str = "") -> str:
+    """Source hash recorded by the last successful build() ("" if there was none)."""
+    path = os.path.join(CSRC, "build" + suffix, "engine.srchash")
+    return open(path).read().strip() if os.path.exists(path) else ""
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """DPTX_CXXFLAGS / DPTX_LIB_SUFFIX (experiments): extra compiler flags and a suffix for the object directory and the
     library name (libdptx<suffix>.so), so that kernel variants can be built side by side; engine.py loads $DPTX_LIB."""

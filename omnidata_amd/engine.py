@@ -89,9 +89,23 @@ _lib = None
 
 
 def load_library() -> C.CDLL:
-    """Loads libdptx.so and declares every prototype.  Raises if the extension is not built."""
+    """Loads libdptx.so and declares every prototype.  The binary must have been built from the sources it sits next to
+    (the .so travels with the tree; mtimes prove nothing on another machine): build.py records the sha256 of csrc/* +
+    include/dptx.h next to the objects and embeds it in the library (dptx_version() ends in "src=<hash>").  A missing or
+    stale library is rebuilt here when hipcc is available (it cross-compiles without a GPU); otherwise -- or if the loaded
+    binary still reports another hash -- this raises.  There is no CPU fallback."""
     global _lib
     if _lib is None:
+        check = not os.environ.get("DPTX_LIB") and not os.environ.get("DPTX_SKIP_HASH_CHECK")
+        if check:
+            from .build import build, built_hash, source_hash
+            want = source_hash(os.environ.get("DPTX_CXXFLAGS", "").split())
+            if not os.path.exists(LIB_PATH) or built_hash() != want:
+                hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+                if not os.path.exists(hipcc):
+                    raise RuntimeError(f"{LIB_PATH} is missing or stale (sources {want}) and {hipcc} is not available: run "
+                                       "`python -m omnidata_amd.build` on a machine with ROCm. There is no CPU fallback.")
+                build()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not found: run `python -m omnidata_amd.build` "
                                "(or __graft_entry__.build()). There is no CPU fallback.")
@@ -100,15 +114,11 @@ def load_library() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        # the binary must have been built from the sources it sits next to (the .so travels with the tree; mtimes do not
-        # prove anything on another machine): dptx_version() ends in "src=<sha256 of csrc/* + include/dptx.h>"
-        if not os.environ.get("DPTX_LIB") and not os.environ.get("DPTX_SKIP_HASH_CHECK"):
-            from .build import source_hash
+        if check:
             built = lib.dptx_version().decode().rsplit("src=", 1)[-1]
-            want = source_hash(os.environ.get("DPTX_CXXFLAGS", "").split())
             if built != want:
                 raise RuntimeError(f"{LIB_PATH} is stale: built from sources {built}, the tree has {want}. "
-                                   "Run `python -m omnidata_amd.build`.")
+                                   "Run `python -m omnidata_amd.build --force`.")
         _lib = lib
     return _lib
 
