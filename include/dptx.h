@@ -99,7 +99,12 @@ typedef struct dptx_config {
  * GROUP_POLICY (dtype MIXED): do not install the default per-LAYER table of the decoder (see dptx_set_layer_precision);
  * every layer then follows its group's bit in x3_groups (round 2's policy: 2.14x the MFMA work of single-pass instead of
  * 1.66x, 1.5-2x smaller deviation from the fp32 forward). */
-enum { DPTX_FLAG_NO_LN_FOLD = 1, DPTX_FLAG_GROUP_POLICY = 2 };
+/* FP32_STREAM: keep the fp32 copy of the ViT token stream in the single-pass dtypes (BF16 / FP16 / FP8).  By default these
+ * dtypes, with the LayerNorm fold, carry the residual stream of the 12 blocks only as the 16-bit tensor that the qkv / fc1
+ * GEMMs multiply (what the reference itself does under model.half() / .bfloat16()): the proj / fc2 epilogues move 4 instead
+ * of 10 bytes per element; the deviation from the fp32 forward grows by 1-5 % of itself (profiles/r03_experiments.md).
+ * MIXED and the 3-MFMA dtypes always keep the fp32 stream. */
+enum { DPTX_FLAG_NO_LN_FOLD = 1, DPTX_FLAG_GROUP_POLICY = 2, DPTX_FLAG_FP32_STREAM = 4 };
 
 /* Fills *cfg with the reference defaults: C=3, max_batch=32, dtype MIXED (the mode that matches the reference's fp32
  * forward within 1e-3; DPTX_DTYPE_BF16 is the ~1.6x faster throughput mode that does not), device 0, non_negative=1,

@@ -343,6 +343,10 @@ struct dptx_engine {
   // LayerNorm of the ViT blocks folded into the qkv / fc1 GEMMs (include/dptx.h DPTX_FLAG_NO_LN_FOLD): the packed qkv / fc1
   // weights and biases are then the folded ones, so this is fixed at dptx_create
   bool ln_fold = false;
+  // 16-bit token stream (include/dptx.h DPTX_FLAG_FP32_STREAM): with the fold in place the single-pass dtypes need the
+  // residual stream of the ViT blocks only as the 16-bit tensor the qkv / fc1 GEMMs multiply -- Hn IS the stream, the
+  // proj / fc2 epilogues read and write 2 + 2 bytes per element instead of 4 + 4 + 2, and no fp32 copy exists
+  bool stream16 = false;
   // fp8: the second plane of the arena / blob holds the e4m3 copies (byte offset off / 2 inside it) instead of lo planes
   bool two_planes() const {
     return cfg.dtype == DPTX_DTYPE_BF16X3 || cfg.dtype == DPTX_DTYPE_FP16X3 || cfg.dtype == DPTX_DTYPE_MIXED || fp8();
@@ -881,6 +885,7 @@ int Run::forward(const void* x, void* y, void* y2) {
   // copy into Hn and the per-row (sum, sum of squares) records into lnst; qkv / fc1 read Hn and normalise in the epilogue
   float* lnst = (float*)A(E->lnst);
   const int ln_nblk = D_VIT / 128;  // records per token row (6 or 8; the row stride is always 8)
+  const bool s16 = E->stream16;     // Hn is the (16-bit) token stream; X is not written
   group(DPTX_GROUP_EMBED);
   {
     // hybrid: the 1x1 projection of the ResNet's 1/16-resolution map (K = 1024); DPT-Large: timm PatchEmbed, a 16x16
@@ -895,19 +900,21 @@ int Run::forward(const void* x, void* y, void* y2) {
     p.c_rpi = NP; p.c_img_rows = S; p.c_row_off = 1; p.ldc = D_VIT; p.c_fp32 = 1;
     p.R2 = pos; p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
     if (E->ln_fold) { p.C16 = A(E->Hn); p.row_stats = lnst; p.stats_nblk = 8; }
+    if (s16) { p.C = A(E->Hn); p.c_fp32 = 0; p.C16 = nullptr; }  // the 16-bit tensor is the stream itself
     exec_macs += (double)NP * D_VIT * Kp;
     cat_macs[0] += (double)NP * D_VIT * Kp;
     chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
   }
-  chk(launch_cls_rows(E->mode_of(DPTX_GROUP_VIT), E->f(vp + "cls_token"), pos, X, B, S, D_VIT, E->ln_fold ? A(E->Hn) : nullptr,
-                      E->ln_fold ? lnst : nullptr, st),
+  chk(launch_cls_rows(E->mode_of(DPTX_GROUP_VIT), E->f(vp + "cls_token"), pos, s16 ? nullptr : X, B, S, D_VIT,
+                      E->ln_fold ? A(E->Hn) : nullptr, E->ln_fold ? lnst : nullptr, st),
       "cls_rows");
   const int M = B * S;
   const size_t tok_elems = (size_t)M * D_VIT;
   auto tok_tap = [&](int idx, const char* name) {
     if (!E->taps_on) return;
     float* dst = E->d_tok_taps + (size_t)idx * E->tok_tap_stride;
-    if (err == hipSuccess) err = hipMemcpyAsync(dst, X, tok_elems * 4, hipMemcpyDeviceToDevice, st);
+    if (s16) chk(launch_to_f32(E->mode_of(DPTX_GROUP_VIT), A(E->Hn), dst, tok_elems, E->pl, st), "tok_tap");
+    else if (err == hipSuccess) err = hipMemcpyAsync(dst, X, tok_elems * 4, hipMemcpyDeviceToDevice, st);
     E->taps[name] = TapInfo{dst, {B, S, D_VIT, 1}, true, dt};
   };
   tok_tap(0, "tok0");
@@ -921,6 +928,9 @@ int Run::forward(const void* x, void* y, void* y2) {
     p.R1 = R1; p.r1_fp32 = r1_fp32; p.planes = E->pl;
     if (ln == 1) { p.ln_stats = lnst; p.ln_colsum = ln_colsum; p.ln_nblk = ln_nblk; p.ln_eps = 1e-6f; p.ln_inv_dim = 1.0f / (float)K; }
     if (ln == 2) { p.C16 = this->A(E->Hn); p.row_stats = lnst; p.stats_nblk = 8; }
+    if (ln == 2 && s16) {  // in place on the 16-bit stream: every thread reads exactly the elements it then writes
+      p.C = this->A(E->Hn); p.c_fp32 = 0; p.R1 = this->A(E->Hn); p.r1_fp32 = 0; p.C16 = nullptr;
+    }
     exec_macs += (double)S * N * K;
     cat_macs[0] += (double)S * N * K;
     chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
@@ -932,8 +942,8 @@ int Run::forward(const void* x, void* y, void* y2) {
     group(DPTX_GROUP_REASSEMBLE);
     const std::string pp = "pretrained.act_postprocess" + std::to_string(n) + ".";
     float* clsb = (float*)A(E->clsb);
-    chk(launch_readout_cls(dt, X, (long long)S * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT, D_VIT,
-                           E->f(pp + "0.project.0.bias"), clsb, B, D_VIT, D_VIT, E->pl, st),
+    chk(launch_readout_cls(dt, s16 ? (const float*)A(E->Hn) : X, (long long)S * D_VIT, E->w(pp + "0.project.0.weight"), 2 * D_VIT,
+                           D_VIT, E->f(pp + "0.project.0.bias"), clsb, B, D_VIT, D_VIT, E->pl, st, s16 ? 1 : 0),
         "readout_cls");
     // the token GEMM reads a 16-bit image of the fp32 stream: with the LayerNorm fold the last fc2 epilogue has already
     // written it (single-plane: the fold implies single-pass ViT blocks; a 3-MFMA reassemble group then still needs the
@@ -1153,7 +1163,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_FP8 || (cfg->ws_form != 0 && cfg->ws_form != 1) ||
-      (cfg->flags & ~(DPTX_FLAG_NO_LN_FOLD | DPTX_FLAG_GROUP_POLICY)) || cfg->reserved != 0)
+      (cfg->flags & ~(DPTX_FLAG_NO_LN_FOLD | DPTX_FLAG_GROUP_POLICY | DPTX_FLAG_FP32_STREAM)) || cfg->reserved != 0)
     return DPTX_E_INVALID;
   int x3_groups = 0;
   if (cfg->dtype == DPTX_DTYPE_MIXED) {
@@ -1189,6 +1199,9 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
     // fused schedules (include/dptx.h DPTX_FLAG_*; the environment variables are for A/B runs of one binary)
     const char* t = getenv("DPTX_LN_FOLD");
     e->ln_fold = !(cfg->flags & DPTX_FLAG_NO_LN_FOLD) && !(t && t[0] == '0') && !mode_is_x3(e->mode_of(DPTX_GROUP_VIT));
+    t = getenv("DPTX_STREAM16");
+    e->stream16 = e->ln_fold && !(cfg->flags & DPTX_FLAG_FP32_STREAM) && !(t && t[0] == '0') &&
+                  (cfg->dtype == DPTX_DTYPE_BF16 || cfg->dtype == DPTX_DTYPE_FP16 || cfg->dtype == DPTX_DTYPE_FP8);
   }
   {
     const char* t = getenv("DPTX_STREAMS");  // experiments: overrides cfg.streams

@@ -132,13 +132,15 @@ hipError_t launch_head_out(int mode, const void* X, const float* w, const float*
 hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
                             void* y, int io, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream);
 hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, int gw, int C, hipStream_t stream);
-// X16 / stats (optional, LayerNorm fold): 16-bit copy of the rows and their (sum, sum of squares) per 128-column block
+// X16 / stats (optional, LayerNorm fold): 16-bit copy of the rows and their (sum, sum of squares) per 128-column block; X may
+// be null (16-bit token stream: no fp32 copy)
 hipError_t launch_cls_rows(int mode, const float* cls, const float* pos, float* X, int B, int S, int C, void* X16, float* stats,
                            hipStream_t stream);
 
 // out[b][n] = bias[n] + sum_k x[b*x_stride + k] * W[n*ldw + w_off + k]   (x fp32, W 16-bit, out fp32)
+// x16 != 0: x points at 16-bit values (the 16-bit token stream of the single-pass dtypes)
 hipError_t launch_readout_cls(int mode, const float* x, long long x_stride, const void* W, int ldw, int w_off,
-                              const float* bias, float* out, int B, int N, int K, Planes pl, hipStream_t stream);
+                              const float* bias, float* out, int B, int N, int K, Planes pl, hipStream_t stream, int x16 = 0);
 // fp32 -> 16-bit (hi/lo planes in bf16x3 mode), n % 8 == 0
 hipError_t launch_cast_f32(int mode, const float* src, void* dst, size_t n, Planes pl, hipStream_t stream);
 

@@ -143,7 +143,7 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
     float v = 0.f;
     if (c < C) {
       v = cls[c] + pos[c];
-      X[(long long)b * S * C + c] = v;
+      if (X) X[(long long)b * S * C + c] = v;
       if (X16) X16[(long long)b * S * C + c] = T16<DT>::fromf(v);
     }
     if (stats) {  // fixed-order reduction: wave sums, then the two waves of a 128-column block
@@ -197,11 +197,12 @@ hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, in
 // cat(tok, cls) @ W^T = tok @ W[:, :768]^T + cls @ W[:, 768:]^T : the second term is one
 // vector per image, computed here and consumed as a per-image bias by the token GEMM.
 // One wave per (image, output feature).
+// x16 != 0: x is the 16-bit token stream (single-pass dtypes keep no fp32 copy of it)
 template <int DT, int PL>
 __global__ __launch_bounds__(256) void readout_cls_kernel(const float* __restrict__ x, long long x_stride,
                                                           const uint16_t* __restrict__ W, int ldw, int w_off,
                                                           const float* __restrict__ bias, float* __restrict__ out, int B, int N,
-                                                          int K, long long wplane) {
+                                                          int K, long long wplane, int x16) {
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (idx >= B * N) return;
@@ -210,7 +211,14 @@ __global__ __launch_bounds__(256) void readout_cls_kernel(const float* __restric
   const uint16_t* wr = W + (long long)n * ldw + w_off;
   float acc = 0.f;
   for (int k = lane * 4; k < K; k += 256) {
-    const float4 xv = *(const float4*)(xr + k);
+    float4 xv;
+    if (x16) {
+      const uint2 xh = *(const uint2*)((const uint16_t*)x + (long long)b * x_stride + k);
+      xv = make_float4(T16<DT>::tof((uint16_t)(xh.x & 0xffffu)), T16<DT>::tof((uint16_t)(xh.x >> 16)),
+                       T16<DT>::tof((uint16_t)(xh.y & 0xffffu)), T16<DT>::tof((uint16_t)(xh.y >> 16)));
+    } else {
+      xv = *(const float4*)(xr + k);
+    }
     const uint2 wv = *(const uint2*)(wr + k);
     float w0 = T16<DT>::tof((uint16_t)(wv.x & 0xffffu)), w1 = T16<DT>::tof((uint16_t)(wv.x >> 16));
     float w2 = T16<DT>::tof((uint16_t)(wv.y & 0xffffu)), w3 = T16<DT>::tof((uint16_t)(wv.y >> 16));
@@ -226,11 +234,11 @@ __global__ __launch_bounds__(256) void readout_cls_kernel(const float* __restric
 }
 
 hipError_t launch_readout_cls(int mode, const float* x, long long x_stride, const void* W, int ldw, int w_off,
-                              const float* bias, float* out, int B, int N, int K, Planes pl, hipStream_t stream) {
+                              const float* bias, float* out, int B, int N, int K, Planes pl, hipStream_t stream, int x16) {
   if (K % 4 != 0 || w_off % 4 != 0 || ldw % 4 != 0) return hipErrorInvalidValue;
   dim3 grid((B * N + 3) / 4);
   DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((readout_cls_kernel<DT, PL>), grid, dim3(256), 0, stream, x, x_stride,
-                                              (const uint16_t*)W, ldw, w_off, bias, out, B, N, K, pl.w));
+                                              (const uint16_t*)W, ldw, w_off, bias, out, B, N, K, pl.w, x16));
   return hipGetLastError();
 }
 

@@ -159,7 +159,7 @@ class Engine:
         cfg.streams = int(streams)
         cfg.x3_groups = groups_mask(x3_groups)  # dtype "mixed": groups that run 3 MFMAs per product (0 = all but the ViT blocks)
         cfg.backbone = BACKBONE_IDS[backbone]
-        cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold, 2: group-level precision policy only)
+        cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold, 2: group-level precision policy only, 4: fp32 token stream in the single-pass dtypes)
         self.cfg = cfg
         self.fp8_calibrated = False
         self.dtype = dtype
