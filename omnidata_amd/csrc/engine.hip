@@ -913,8 +913,12 @@ int Run::forward(const void* x, void* y, void* y2) {
   auto tok_tap = [&](int idx, const char* name) {
     if (!E->taps_on) return;
     float* dst = E->d_tok_taps + (size_t)idx * E->tok_tap_stride;
-    if (s16) chk(launch_to_f32(E->mode_of(DPTX_GROUP_VIT), A(E->Hn), dst, tok_elems, E->pl, st), "tok_tap");
-    else if (err == hipSuccess) err = hipMemcpyAsync(dst, X, tok_elems * 4, hipMemcpyDeviceToDevice, st);
+    if (s16) {  // debug copy: not a launch of the schedule (not counted, not timed)
+      const hipError_t r = launch_to_f32(E->mode_of(DPTX_GROUP_VIT), A(E->Hn), dst, tok_elems, E->pl, st);
+      if (err == hipSuccess && r != hipSuccess) { err = r; where = "tok_tap"; }
+    } else if (err == hipSuccess) {
+      err = hipMemcpyAsync(dst, X, tok_elems * 4, hipMemcpyDeviceToDevice, st);
+    }
     E->taps[name] = TapInfo{dst, {B, S, D_VIT, 1}, true, dt};
   };
   tok_tap(0, "tok0");
