@@ -1356,7 +1356,12 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
   const int C = h->cfg.num_channels;
   const size_t esz = io == DPTX_IO_FP32 ? 4 : 2;  // bytes per element of the caller's buffers
   const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling && !h->calibrating;
+  // tile selection of the GEMMs (kernels.h gemm_set_cu_share): a sub-batch run shares the chip with the other streams' runs.
+  // DPTX_CU_SHARE overrides (A/B runs: 1 = tile every launch for the whole chip, as rounds 1-2 did)
+  static float share_env = -1.f;
+  if (share_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE"); share_env = t ? (float)atof(t) : 0.f; }
   if (!split) {
+    gemm_set_cu_share(1.0f);
     Run run{h, batch, stream, h->cfg.dtype, height, width, io};
     const int rc = run.forward(x, y, y2);
     h->launches = run.launches;
@@ -1366,6 +1371,7 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
     return rc;
   }
   const int nr = batch < h->n_streams ? batch : h->n_streams;  // sub-batches: the first (batch % nr) get one image more
+  gemm_set_cu_share(share_env > 0.f ? share_env : 1.0f / (float)nr);
   if (!h->ev_fork) {
     for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
       HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));
@@ -1396,6 +1402,7 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
     HIPCHK(h, hipStreamWaitEvent(stream, h->ev_join[r], 0));
     first += (size_t)nb;
   }
+  gemm_set_cu_share(1.0f);
   h->taps.clear();  // stage taps describe whole-batch runs only (dptx_enable_taps makes the forward single-pass)
   h->launches = launches;
   h->last_batch = batch;

@@ -1159,6 +1159,11 @@ template <int DT, int PL, int PLE = PL>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
   const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
+  // cu_share: the part of the chip this launch can count on -- 1/n when the forward runs as n sub-batches on n streams (the
+  // other streams' launches occupy the rest), so that a half-batch GEMM is tiled for half the CUs instead of being judged
+  // too small for the wide tiles: CU slots and tile-count thresholds scale with it
+  const double sh = p.cu_share > 0.f ? (double)p.cu_share : 1.0;
+  const long long cu1 = (long long)(256 * sh + 0.5), cu2 = (long long)(512 * sh + 0.5);  // slots at 1 / 2 blocks per CU
   static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (tools/gemm_bench.py)
   if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
   {
@@ -1180,25 +1185,25 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   if constexpr (PL == 1) {
     const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
     if (forced != 128 && glds_ok && p.N % 256 == 0 && p.K >= 512) {
-      const long long t256 = m256 * (p.N / 256), r256 = (t256 + 255) / 256;
-      const long long t128 = m128 * (p.N / 128), r128 = (t128 + 511) / 512;
-      const double fill256 = (double)t256 / (double)(r256 * 256), fill128 = (double)t128 / (double)(r128 * 512);
-      if (t256 >= 200 && fill256 * 1.25 >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4, PLE>(p, stream);
+      const long long t256 = m256 * (p.N / 256), r256 = (t256 + cu1 - 1) / cu1;
+      const long long t128 = m128 * (p.N / 128), r128 = (t128 + cu2 - 1) / cu2;
+      const double fill256 = (double)t256 / (double)(r256 * cu1), fill128 = (double)t128 / (double)(r128 * cu2);
+      if (t256 >= 200 * sh && fill256 * 1.25 >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4, PLE>(p, stream);
     }
   }
   if constexpr (PL == 2) {
     // 3-MFMA modes are one block per CU (two planes of two stages = 128 KB of LDS); eight waves (2 x 4, wave tile
     // 64 x 32) instead of four put two waves on every SIMD, so that one's fragment reads overlap the other's MFMAs:
     // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md)
-    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200) return launch_cfg<DT, PL, 128, 128, 2, 4, PLE>(p, stream);
+    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200 * sh) return launch_cfg<DT, PL, 128, 128, 2, 4, PLE>(p, stream);
   }
   // (row_stats -- the producer side of the LayerNorm fold -- reduces 128-column blocks inside a tile: never narrower tiles)
   // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
   // 128x64 by 2..10 %, whose second round is nearly empty
-  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE>(p, stream);
+  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 * sh || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE>(p, stream);
   if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1, PLE>(p, stream);
-  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 256, 64, 4, 1, PLE>(p, stream);
-  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE>(p, stream);
+  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448 * sh) return launch_cfg<DT, PL, 256, 64, 4, 1, PLE>(p, stream);
+  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448 * sh) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE>(p, stream);
   if (p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE>(p, stream);
   return hipErrorInvalidValue;
 }
