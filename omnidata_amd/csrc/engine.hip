@@ -1358,8 +1358,9 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
   const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling && !h->calibrating;
   // tile selection of the GEMMs (kernels.h gemm_set_cu_share): a sub-batch run shares the chip with the other streams' runs.
   // DPTX_CU_SHARE overrides (A/B runs: 1 = tile every launch for the whole chip, as rounds 1-2 did)
-  static float share_env = -1.f;
+  static float share_env = -1.f, share_small_env = -1.f;
   if (share_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE"); share_env = t ? (float)atof(t) : 0.f; }
+  if (share_small_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE_SMALL"); share_small_env = t ? (float)atof(t) : 0.f; }
   if (!split) {
     gemm_set_cu_share(1.0f);
     Run run{h, batch, stream, h->cfg.dtype, height, width, io};
@@ -1371,7 +1372,7 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
     return rc;
   }
   const int nr = batch < h->n_streams ? batch : h->n_streams;  // sub-batches: the first (batch % nr) get one image more
-  gemm_set_cu_share(share_env > 0.f ? share_env : 1.0f / (float)nr);
+  gemm_set_cu_share(share_env > 0.f ? share_env : 1.0f / (float)nr, share_small_env > 0.f ? share_small_env : 0.f);
   if (!h->ev_fork) {
     for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
       HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));

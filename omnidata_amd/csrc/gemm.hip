@@ -18,13 +18,16 @@ void gemm_params_dense(GemmParams& p, int M, int N, int K) {
 
 static long long* g_trace = nullptr;
 void gemm_set_trace(long long* dev_buf) { g_trace = dev_buf; }
-static thread_local float g_cu_share = 1.0f;
-void gemm_set_cu_share(float share) { g_cu_share = share > 0.f && share <= 1.f ? share : 1.0f; }
+static thread_local float g_cu_share = 1.0f, g_cu_share_small = 1.0f;
+void gemm_set_cu_share(float share, float share_small) {
+  g_cu_share = share > 0.f && share <= 1.f ? share : 1.0f;
+  g_cu_share_small = share_small > 0.f && share_small <= 1.f ? share_small : g_cu_share;
+}
 
 hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   p.trace = g_trace;
-  if (p.cu_share <= 0.f) p.cu_share = g_cu_share;
+  if (p.cu_share <= 0.f) { p.cu_share = g_cu_share; p.cu_share_small = g_cu_share_small; }
   p.a_rpi_rcp = 1.0f / (float)(p.a_rpi > 0 ? p.a_rpi : 1);
   p.wout_rcp = 1.0f / (float)(p.Wout > 0 ? p.Wout : 1);
   if (p.gn_part != nullptr && (p.gn_hw % 32 != 0 || p.N % 32 != 0 || p.gn_cpg != p.N / 32 || p.gn_cpg < 2 || p.gn_cpg > 32 ||

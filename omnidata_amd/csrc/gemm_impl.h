@@ -1163,6 +1163,7 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // other streams' launches occupy the rest), so that a half-batch GEMM is tiled for half the CUs instead of being judged
   // too small for the wide tiles: CU slots and tile-count thresholds scale with it
   const double sh = p.cu_share > 0.f ? (double)p.cu_share : 1.0;
+  const double shs = p.cu_share_small > 0.f ? (double)p.cu_share_small : sh;  // for the narrow-tile thresholds
   const long long cu1 = (long long)(256 * sh + 0.5), cu2 = (long long)(512 * sh + 0.5);  // slots at 1 / 2 blocks per CU
   static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (tools/gemm_bench.py)
   if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
@@ -1195,15 +1196,15 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
     // 3-MFMA modes are one block per CU (two planes of two stages = 128 KB of LDS); eight waves (2 x 4, wave tile
     // 64 x 32) instead of four put two waves on every SIMD, so that one's fragment reads overlap the other's MFMAs:
     // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md)
-    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200 * sh) return launch_cfg<DT, PL, 128, 128, 2, 4, PLE>(p, stream);
+    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200 * shs) return launch_cfg<DT, PL, 128, 128, 2, 4, PLE>(p, stream);
   }
   // (row_stats -- the producer side of the LayerNorm fold -- reduces 128-column blocks inside a tile: never narrower tiles)
   // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
   // 128x64 by 2..10 %, whose second round is nearly empty
-  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 * sh || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE>(p, stream);
+  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 * shs || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE>(p, stream);
   if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1, PLE>(p, stream);
-  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448 * sh) return launch_cfg<DT, PL, 256, 64, 4, 1, PLE>(p, stream);
-  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448 * sh) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE>(p, stream);
+  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448 * shs) return launch_cfg<DT, PL, 256, 64, 4, 1, PLE>(p, stream);
+  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448 * shs) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE>(p, stream);
   if (p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE>(p, stream);
   return hipErrorInvalidValue;
 }

@@ -44,7 +44,8 @@ struct GemmParams {
   // also of the 3-MFMA kernels) switch off the lo plane of C / R1 / R2 individually
   int epi2, c_hi_only, r1_hi_only, r2_hi_only;
   int xcd_m, xcd_n;  // XCD grid of the tile partition (filled in by launch_gemm)
-  float cu_share;    // part of the chip this launch can count on (filled in by launch_gemm from gemm_set_cu_share; 0 = 1)
+  float cu_share, cu_share_small;  // part of the chip this launch can count on, for the 256x256 rule / the narrow-tile
+                                   // thresholds (filled in by launch_gemm from gemm_set_cu_share; 0 = 1)
   int k_tap_fast;    // visit the k-tiles taps-fastest inside a 64-channel block (3x3 convs with Cin >= 512: +12..17 %)
   // GroupNorm(32) statistics of the output from the epilogue (null: none): partial[img][gn_blocks][32] float2 records
   // of (sum, sum of squares) per 32-row block; gn_hw = rows per image (% 32 == 0), gn_cpg = N / 32 channels per group
@@ -87,7 +88,7 @@ hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 // ([wave][64 k-tiles][4] int64; null switches it off)
 void gemm_set_trace(long long* dev_buf);
 // tile selection: the following launches share the chip with (1 / share - 1) concurrent streams of the same forward
-void gemm_set_cu_share(float share);
+void gemm_set_cu_share(float share, float share_small = 0.f);
 
 hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, int heads, Planes pl, hipStream_t stream);
 
