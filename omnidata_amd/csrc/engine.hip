@@ -10,6 +10,7 @@
 // timm 0.4.12 vit_base_resnet50_384 (vit.py:483) is restated per SURVEY.md A.2.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1357,7 +1358,10 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
   const size_t esz = io == DPTX_IO_FP32 ? 4 : 2;  // bytes per element of the caller's buffers
   const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling && !h->calibrating;
   // tile selection of the GEMMs (kernels.h gemm_set_cu_share): a sub-batch run shares the chip with the other streams' runs.
-  // DPTX_CU_SHARE overrides (A/B runs: 1 = tile every launch for the whole chip, as rounds 1-2 did)
+  // Measured (profiles/r03_experiments.md, two streams): judging the 256x256 rule against 0.7 of the chip -- which moves the
+  // half-batch qkv GEMM (333 tiles) from the 128x128 kernel to the ping-pong kernel -- is worth +1.2 % (bf16) / +1.3 % (mixed);
+  // 0.5 (proj / fc2 at 111 tiles too) and scaled narrow-tile thresholds lose.  DPTX_CU_SHARE / DPTX_CU_SHARE_SMALL override
+  // (1 = tile every launch for the whole chip, as rounds 1-2 did)
   static float share_env = -1.f, share_small_env = -1.f;
   if (share_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE"); share_env = t ? (float)atof(t) : 0.f; }
   if (share_small_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE_SMALL"); share_small_env = t ? (float)atof(t) : 0.f; }
@@ -1372,7 +1376,7 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
     return rc;
   }
   const int nr = batch < h->n_streams ? batch : h->n_streams;  // sub-batches: the first (batch % nr) get one image more
-  gemm_set_cu_share(share_env > 0.f ? share_env : 1.0f / (float)nr, share_small_env > 0.f ? share_small_env : 0.f);
+  gemm_set_cu_share(share_env > 0.f ? share_env : std::min(1.0f, 1.4f / (float)nr), share_small_env > 0.f ? share_small_env : 1.0f);
   if (!h->ev_fork) {
     for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
       HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));
