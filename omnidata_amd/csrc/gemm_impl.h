@@ -199,7 +199,10 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
 // the four 128-row half-tiles of a k-tile are needed one phase after the other.
 template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
-                                         int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0) {
+                                         int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0, bool dma_in_flight = false) {
+  // dma_in_flight (persistent gemm_pp_kernel): the caller has LDS-DMA of its next tile outstanding; the epilogue waits for
+  // it together with its own first loads, BEFORE its first store (stores count in vmcnt on gfx9: a vmcnt(0) after them
+  // would wait for the tile to reach memory)
   // row_pitch != 0 (gemm_halo_kernel): the tile is 8 image rows x 32 pixels -- tile row R is GEMM row
   // m0 + (R >> 5) * row_pitch + (R & 31)
   static_assert(SLABS == 1 || SLABS == TM, "one slab, or one per MFMA row tile");
@@ -259,6 +262,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
     }
   }
   const bool remap = p.c_rpi != 0x7fffffff;  // token-row remap (patch-embed, readout); everything else skips the division
+  int c_rpi = p.c_rpi;
+  asm volatile("" : "+s"(c_rpi));  // opaque: inside a tile loop the divider's reciprocal would be hoisted into live registers
   // LayerNorm fold, consumer side: (mu, rstd) of the tile's BM rows, combined ONCE per row from its (sum, sum of squares)
   // records (row stride 8 records, ln_nblk = 6 or 8 valid) into an LDS table behind the C tile -- every row is needed by
   // the 32 (16) threads that own its columns, in every n-tile: per-thread combining cost 64 sixteen-byte loads per thread
@@ -284,9 +289,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   }
   // rows per load group: 4 (96 registers of loads in flight at most); 2 for the slab epilogue, whose 128 accumulator
   // registers stay live across the slabs
-  constexpr int GR = SLABS > 1 ? 2 : (ITER < 4 ? ITER : 4);
-  constexpr int NGR = ITER / GR;
-  static_assert(ITER % GR == 0, "row groups");
+  constexpr int GR_ = SLABS > 1 ? 2 : (ITER < 4 ? ITER : 4);
+  static_assert(ITER % GR_ == 0, "row groups");
 
   // The body is instantiated per residual configuration (R1M / R2M: 0 none, 1 16-bit, 2 fp32, -1 decided at run time;
   // BPI: per-image bias 0 / 1 / -1) and selected by ONE uniform branch below: inside an instance the loads are
@@ -295,6 +299,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   auto body = [&](auto r1m_, auto r2m_, auto bpi_, auto lnf_) {
     constexpr int R1M = decltype(r1m_)::value, R2M = decltype(r2m_)::value, BPI = decltype(bpi_)::value;
     constexpr bool LNF = decltype(lnf_)::value != 0;  // LayerNorm folded into this GEMM (consumer side, kernels.h)
+    // the run-time-decided instance of the slab epilogue (patch-embed, readout: five launches per forward) holds three load
+    // sets per row: one row per group, or it spills inside the persistent tile loop of gemm_pp_kernel
+    // (likewise the two-plane epilogue with two residuals: four 16-byte loads per row)
+    constexpr int GR = (SLABS > 1 && (R1M < 0 || (PL == 2 && R1M != 0 && R2M != 0))) ? 1 : GR_;
+    constexpr int NGR = ITER / GR;
     float ln_c[8];  // colsum of the folded weight for this thread's 8 columns
     if (LNF) {
       const float4 c0 = *(const float4*)(p.ln_colsum + n), c1 = *(const float4*)(p.ln_colsum + n + 4);
@@ -324,8 +333,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         m = ok[it] ? m : m0;  // any valid row: the loads stay in bounds, the store is masked
         int img = 0, pp = m;
         if (remap) {
-          img = m / p.c_rpi;
-          pp = m - img * p.c_rpi;
+          img = m / c_rpi;
+          pp = m - img * c_rpi;
         }
         const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
         coff[it] = crow * p.ldc + n;
@@ -382,6 +391,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             ct[ml * CT_PITCH + nl] = acc[i][j][r];
           }
       }
+      if (s == 0 && dma_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       // ---- (c) rows out
 #pragma unroll
@@ -726,59 +736,78 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   constexpr int SLABS = TM;
   constexpr int HALF = 128 * 128;  // bytes of a 128-row operand tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // group = wm
-  const int lr = lane & 31, lh = lane >> 5;
+  // Thread coordinates.  They are re-derived from an opaque copy of threadIdx at the top of every tile (DPTX_PP_COORDS) so
+  // that none of them -- nor anything computed from them -- has to stay in a register across the epilogue, whose slab loop
+  // needs every register next to the 128 accumulators.
+  int tid = threadIdx.x;
+  int lane, wave, wm, wn, lr, lh;   // wm = wave group
+  int t, kc, r0, sc, a_row0, wq;    // loader coordinates, below
+#define DPTX_PP_COORDS()                                                                                           \
+  do {                                                                                                             \
+    asm volatile("" : "+v"(tid));                                                                                  \
+    lane = tid & 63;                                                                                               \
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                               \
+    wm = wave >> 2; wn = wave & 3;                                                                                 \
+    lr = lane & 31; lh = lane >> 5;                                                                                \
+    t = tid & 255;                                                                                                 \
+    kc = t & 7; r0 = t >> 3;                                                                                       \
+    sc = kc ^ ((r0 >> 1) & 7);                                                                                     \
+    a_row0 = wm == 0 ? 128 : 0;                                                                                    \
+    wq = wave & 3;     /* wave inside its group: rows 8*wq .. 8*wq+7 of every 32-row pass */                       \
+  } while (0)
+  DPTX_PP_COORDS();
   // LDS map: stage b = [A rows 0..127 | A rows 128..255 | W rows 0..255] at b * 64 KB
   auto w_ptr = [&](int b) -> char* { return smem + b * 4 * HALF + 2 * HALF; };
   auto alo_ptr = [&](int b) -> char* { return smem + b * 4 * HALF; };
   auto ahi_ptr = [&](int b) -> char* { return smem + b * 4 * HALF + HALF; };
 
+  // Tile loop: XCD x = blockIdx % 8 owns a 2-D slice of the tile grid (launch_cfg); block l of the XCD takes the slice's
+  // tiles l, l + L, l + 2L, ... (L = gridDim / 8 blocks per XCD).  A launch with one block per tile (L = tiles per slice)
+  // runs the loop once; the persistent launch (L = 32: one block per CU) keeps the block and overlaps a tile's epilogue --
+  // the LDS transposition of the accumulators, the residual loads, the stores draining to HBM -- with the landing of the
+  // next tile's first k-tile.  Which block computes a tile does not change the tile's arithmetic: results are bit-identical.
   const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int xcd = (int)blockIdx.x & 7, lstep = (int)gridDim.x >> 3;
+  const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
+  const int ltot = tm_per * tn_per;
+  const int mt_base = (xcd / p.xcd_n) * tm_per, nt_base = (xcd % p.xcd_n) * tn_per;
+  int l = (int)blockIdx.x >> 3;
+  if (l >= ltot || mt_base + l / tn_per >= tiles_m) return;
   int m0, n0;
-  {
-    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
-    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
-    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
-    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
-    if (mt >= tiles_m || l >= tm_per * tn_per) return;
-    m0 = mt * BM;
-    n0 = nt * BN;
-  }
 
   // loader of a group: thread (r0 = t>>3, kc = t&7), t = tid % 256, owns LDS chunk kc of rows base + r0 + 32*i.
   // Group 0 loads A rows 128..255 (4 passes) and W rows 0..255 (8 passes); group 1 loads A rows 0..127 (4 passes).
-  const int t = tid & 255;
-  const int kc = t & 7, r0 = t >> 3;
-  const int sc = kc ^ ((r0 >> 1) & 7);
-  const int a_row0 = wm == 0 ? 128 : 0;
   int a_iy0[4], a_ix0[4];
   unsigned a_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + a_row0 + r0 + 32 * i;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    int rem, ox;
-    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
-    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
-    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
-    a_ix0[i] = ox * p.stride - p.pad_l;
-    const long long e = (long long)img * p.a_img_stride + p.a_off + ((long long)a_iy0[i] * p.Win + a_ix0[i]) * p.a_pix_stride + sc * 8;
-    a_off[i] = (unsigned)(ok ? e * 2 : 0);
-  }
   unsigned w_off[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) w_off[j] = (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2);
+  // addressing of tile `l` of this XCD's slice
+#define DPTX_PP_TILE_SETUP()                                                                                       \
+  do {                                                                                                             \
+    m0 = (mt_base + l / tn_per) * BM;                                                                              \
+    n0 = (nt_base + l % tn_per) * BN;                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+      const int m = m0 + a_row0 + r0 + 32 * i;                                                                     \
+      const bool ok = m < p.M;                                                                                     \
+      const int mm = ok ? m : 0;                                                                                   \
+      int rem, ox;                                                                                                 \
+      const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);                                               \
+      const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);                                                  \
+      a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;                                                       \
+      a_ix0[i] = ox * p.stride - p.pad_l;                                                                          \
+      /* element offset mod 2^32 (the buffer is < 2^31 bytes: launch_cfg) */                                       \
+      const unsigned e = (unsigned)img * (unsigned)p.a_img_stride + (unsigned)p.a_off +                            \
+                         (unsigned)(a_iy0[i] * p.Win + a_ix0[i]) * (unsigned)p.a_pix_stride + (unsigned)(sc * 8);  \
+      a_off[i] = ok ? e * 2u : 0u;                                                                                 \
+    }                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
+      w_off[j] = (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2);                                 \
+  } while (0)
   const int w_bytes = (int)((long long)p.N * p.ldw * 2);
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
 
   // tap / channel offset (wave-uniform) of the k-tile whose A rows this group loads next, and (group 0) whose W rows
   int ky = 0, kx = 0, c0 = 0, kyw = 0, kxw = 0, c0w = 0;
-  const int wq = wave & 3;     // wave inside its group: rows 8*wq .. 8*wq+7 of every 32-row pass
 #define DPTX_PP_NEXT(KY, KX, C0)                                                                                   \
   do {                                                                                                             \
     if (p.k_tap_fast) {                                                                                            \
@@ -812,14 +841,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     DPTX_PP_NEXT(kyw, kxw, c0w);                                                                                   \
   } while (0)
 
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int nk = p.K / BK;
   const bool tr = p.trace != nullptr && blockIdx.x == 0 && lane == 0;
   long long* trp = p.trace + wave * 4 * 64;
@@ -830,63 +851,104 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #define DPTX_STAMP(SLOT) do { } while (0)
   (void)tr; (void)trp;
 #endif
-  // prologue: tile 0
-  if (wm == 0) {
-    DPTX_PP_ISSUE_W(w_ptr(0));
-    DPTX_PP_ISSUE_A(ahi_ptr(0));
-  } else {
-    DPTX_PP_ISSUE_A(alo_ptr(0));
-  }
+  // the first k-tile of the tile at (ky, kx, c0) = 0 into stage 0
+#define DPTX_PP_PROLOGUE()                                                                                         \
+  do {                                                                                                             \
+    ky = kx = c0 = kyw = kxw = c0w = 0;                                                                            \
+    if (wm == 0) {                                                                                                 \
+      DPTX_PP_ISSUE_W(w_ptr(0));                                                                                   \
+      DPTX_PP_ISSUE_A(ahi_ptr(0));                                                                                 \
+    } else {                                                                                                       \
+      DPTX_PP_ISSUE_A(alo_ptr(0));                                                                                 \
+    }                                                                                                              \
+  } while (0)
+  DPTX_PP_TILE_SETUP();
+  DPTX_PP_PROLOGUE();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
-  // that hipcc resolves with copies: 500 spilled registers)
-  PpFrags f0, f1;
-  if (wm == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      DPTX_STAMP(0);
-      // slot 1: the DMA -- W and A rows 128..255 of tile kt+1
-      const char* sa = alo_ptr(kt & 1);
-      const char* sb = w_ptr(kt & 1);
-      if (kt + 1 < nk) {
-        DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
-        DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));
+  for (;;) {
+    // the tile's addressing is (re)computed here from l: it must not stay live across the epilogue, whose slab loop needs
+    // every register next to the 128 accumulators (the asm makes l opaque, so the values above are not carried over)
+    asm volatile("" : "+s"(l));
+    DPTX_PP_COORDS();
+    DPTX_PP_TILE_SETUP();
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // every wave has waited for its own pieces of k-tile 0 (above / inside the previous tile's epilogue) and is done with the
+    // epilogue's LDS tile, which the DMA of k-tile 1 overwrites
+    __syncthreads();
+    // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
+    // that hipcc resolves with copies: 500 spilled registers)
+    PpFrags f0, f1;
+    if (wm == 0) {
+      for (int kt = 0; kt < nk; ++kt) {
+        DPTX_STAMP(0);
+        // slot 1: the DMA -- W and A rows 128..255 of tile kt+1
+        const char* sa = alo_ptr(kt & 1);
+        const char* sb = w_ptr(kt & 1);
+        if (kt + 1 < nk) {
+          DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
+          DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));
+        }
+        DPTX_STAMP(1);
+        asm volatile("s_barrier" ::: "memory");
+        DPTX_STAMP(2);
+        pp_read(f0, sa, sb, wn, lr, lh, 0);            // slot 2
+        pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what group 1 reads in its next slot has landed
+        DPTX_STAMP(3);
+        asm volatile("s_barrier" ::: "memory");
       }
-      DPTX_STAMP(1);
-      asm volatile("s_barrier" ::: "memory");
-      DPTX_STAMP(2);
-      pp_read(f0, sa, sb, wn, lr, lh, 0);            // slot 2
-      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what group 1 reads in its next slot has landed
-      DPTX_STAMP(3);
-      asm volatile("s_barrier" ::: "memory");
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        DPTX_STAMP(0);
+        const char* sa = ahi_ptr(kt & 1);              // slot 1
+        const char* sb = w_ptr(kt & 1);
+        pp_read(f0, sa, sb, wn, lr, lh, 0);
+        pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its DMA of the previous slot 2 (A rows 0..127 of THIS
+        DPTX_STAMP(1);                                    // tile) has landed before group 0 reads it in slot 2
+        asm volatile("s_barrier" ::: "memory");
+        DPTX_STAMP(2);
+        if (kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
+        DPTX_STAMP(3);
+        asm volatile("s_barrier" ::: "memory");
+      }
     }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      DPTX_STAMP(0);
-      const char* sa = ahi_ptr(kt & 1);              // slot 1
-      const char* sb = w_ptr(kt & 1);
-      pp_read(f0, sa, sb, wn, lr, lh, 0);
-      pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its DMA of the previous slot 2 (A rows 0..127 of THIS
-      DPTX_STAMP(1);                                    // tile) has landed before group 0 reads it in slot 2
-      asm volatile("s_barrier" ::: "memory");
-      DPTX_STAMP(2);
-      if (kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
-      DPTX_STAMP(3);
-      asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave is done reading both stages
+    // next tile of this block: its first k-tile flies into stage 0 under this tile's epilogue, which stages the accumulators
+    // through the memory of stage 1 (+ 4.6 KB behind it)
+    const int em0 = m0, en0 = n0;
+    l += lstep;
+    const bool more = l < ltot && mt_base + l / tn_per < tiles_m;
+    if (more) {
+      DPTX_PP_TILE_SETUP();
+      DPTX_PP_PROLOGUE();
     }
+    {
+      // opaque copies of the thread coordinates: the epilogue's per-thread addresses are the same for every tile, and hoisted
+      // out of the tile loop they would occupy ~40 registers through the k-loop (scratch spills)
+      int etid = tid, elr = lr, elh = lh, ewm = wm, ewn = wn;
+      asm volatile("" : "+v"(etid), "+v"(elr), "+v"(elh), "+s"(ewm), "+s"(ewn));
+      epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more);
+    }
+    if (!more) break;
   }
 #ifdef DPTX_TRACE
   if (tr && wave == 0) { trp[62 * 4 + 2] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 3] = (long long)wall_clock64(); }
 #endif
 #undef DPTX_STAMP
+#undef DPTX_PP_PROLOGUE
+#undef DPTX_PP_TILE_SETUP
+#undef DPTX_PP_COORDS
 #undef DPTX_PP_ISSUE_W
 #undef DPTX_PP_ISSUE_A
 #undef DPTX_PP_NEXT
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
 #endif
 }
 
@@ -1107,9 +1169,18 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr bool pp = true;
 #endif
     if (pp && glds_ok) {  // ping-pong schedule of the two wave groups (gemm_pp_kernel)
+      // persistent launch: at most 32 blocks per XCD (one per CU), each looping over its XCD slice's tiles; the epilogue's
+      // LDS tile sits behind stage 0 (which receives the next tile's first k-tile meanwhile).  DPTX_PERSIST=0: one block per
+      // tile (A/B runs; same kernel, same results); DPTX_PERSIST=n: n blocks per XCD
+      static int per_xcd = -1;
+      if (per_xcd < 0) { const char* e = getenv("DPTX_PERSIST"); per_xcd = e ? atoi(e) : 32; }
+      const int ltot = tiles / 8;
+      const int grid = per_xcd > 0 && ltot > per_xcd ? 8 * per_xcd : tiles;
+      constexpr size_t smem_pp = (size_t)256 * 256 + (size_t)64 * (BN + 4) * 4 + (size_t)BM * 8;
+      static_assert(smem_pp >= smem && smem_pp <= 160 * 1024, "stage 0 + the epilogue's slab and row table");
       auto go = [&](auto k) {
-        set_smem_attr(k, smem);
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
+        set_smem_attr(k, smem_pp);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem_pp, stream, q);
       };
       if (p.a_relu) go(gemm_pp_kernel<DT, true, PLE>);
       else go(gemm_pp_kernel<DT, false, PLE>);
