@@ -6,7 +6,7 @@ O=$R/gpurun_out/r3i
 mkdir -p $O
 export TMPDIR=/tmp
 # correctness first: op-level GEMM / conv tests and the end-to-end oracle comparisons run on the persistent kernel (default)
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_e2e.py tests/test_gpu_mixed.py -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_e2e.py -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
 SH="vit.qkv,vit.proj,vit.fc1,vit.fc2,patch.proj,cal.8192,rcu@96,rcu@48,head.0,l2_rn,l3_rn,s2.c2,pp4.conv2"
 for P in 0 32; do
   DPTX_PERSIST=$P timeout 300 python tools/gemm_bench.py --only $SH > $O/shapes_p$P.txt 2>&1
