@@ -139,9 +139,7 @@ __device__ __forceinline__ uint4 relu8(uint4 v) {
   return v;
 }
 
-// erf-GELU (timm Mlp / ProjectReadout use nn.GELU(), the exact erf form).  erf via Abramowitz &
-// Stegun 7.1.26 (|abs err| < 1.5e-7; measured 4.7e-7 on gelu over [-12,12] in fp32): a dozen VALU
-// ops + v_exp_f32 + v_rcp_f32 instead of libm erff's ~40, which showed up in the fc1 epilogue.
+// erf-GELU (timm Mlp / ProjectReadout use nn.GELU(), the exact erf form): gelu_erf() below.
 // 8 consecutive elements <-> floats, with optional hi/lo planes
 template <int DT, int PL>
 __device__ __forceinline__ void load8f(const uint16_t* p, long long plane, float* f) {
@@ -225,12 +223,25 @@ __device__ __forceinline__ float bilerp(float a, float b, float c, float d, floa
   return __fmaf_rn(ly1, t1, __fmul_rn(ly0, t0));
 }
 
+// erfc via Abramowitz & Stegun 7.1.28, erfc(z) = (1 + a1 z + ... + a6 z^6)^-16 for z >= 0 (|abs err| <= 3e-7; measured
+// 7.1e-7 on gelu over [-12, 12] in fp32, the same league as 7.1.26's 4.7e-7, which round 1-2 used): six fused
+// multiply-adds, four squarings and ONE quarter-rate instruction (v_rcp_f32) -- 7.1.26 needs v_rcp_f32 + v_exp_f32 and as
+// many multiply-adds; everything but the reciprocal packs into v_pk_*_f32.  The fc1 epilogue evaluates this for 56.7 M
+// elements per launch with no MFMA running beside it (~10 us of a 24 us tile with 7.1.26).
+// gelu(x) = x/2 * (1 + erf(x/sqrt 2)) = (h + |h|) - |h| * erfc(|x|/sqrt 2), h = x/2: exact 0 - |h| erfc for x < 0 (no
+// cancellation in the tail); p^16 overflows to inf beyond |x| ~ 24, whose reciprocal is the right limit 0.
 __device__ __forceinline__ float gelu_erf(float x) {
+  const float h = 0.5f * x;
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));  // v_rcp_f32 (1 ulp); __frcp_rn expands to a full division
-  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-  const float e = fmaf(-poly, __expf(-z * z), 1.0f);
-  return 0.5f * x * (1.0f + copysignf(e, x));
+  float q = fmaf(z, 0.0000430638f, 0.0002765672f);
+  q = fmaf(q, z, 0.0001520143f);
+  q = fmaf(q, z, 0.0092705272f);
+  q = fmaf(q, z, 0.0422820123f);
+  q = fmaf(q, z, 0.0705230784f);
+  q = fmaf(q, z, 1.0f);
+  q *= q; q *= q; q *= q; q *= q;
+  const float r = __builtin_amdgcn_rcpf(q);  // erfc(z)
+  return fmaf(-fabsf(h), r, h + fabsf(h));
 }
 
 // Bijective XCD-aware remap of a 1-D block id: blocks that the dispatcher places on one

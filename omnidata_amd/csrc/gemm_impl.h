@@ -199,7 +199,8 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
 // the four 128-row half-tiles of a k-tile are needed one phase after the other.
 template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
-                                         int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0, bool dma_in_flight = false) {
+                                         int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0, bool dma_in_flight = false,
+                                         int trace_row = -1) {
   // dma_in_flight (persistent gemm_pp_kernel): the caller has LDS-DMA of its next tile outstanding; the epilogue waits for
   // it together with its own first loads, BEFORE its first store (stores count in vmcnt on gfx9: a vmcnt(0) after them
   // would wait for the tile to reach memory)
@@ -213,6 +214,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   constexpr int RPP = NT / NCH;   // tile rows per pass
   constexpr int ITER = CT_ROWS / RPP;
   static_assert(CT_ROWS % RPP == 0, "rows per pass must divide the slab");
+#ifdef DPTX_TRACE   // tile-phase stamps of thread 0 of block 0 (tools/gpu/pp_trace.py): rows 48.. of wave 0's trace block
+#define DPTX_ESTAMP(SLOT)                                                                                          \
+  do {                                                                                                             \
+    if (p.trace != nullptr && blockIdx.x == 0 && tid == 0 && trace_row >= 0)                                       \
+      p.trace[(48 + trace_row) * 4 + (SLOT)] = (long long)__builtin_readcyclecounter();                            \
+  } while (0)
+#else
+#define DPTX_ESTAMP(SLOT) do { } while (0)
+  (void)trace_row;
+#endif
+  DPTX_ESTAMP(0);
   float* ct = (float*)smem;
   const int cn = tid % NCH;
   const int rr = tid / NCH;
@@ -287,6 +299,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       lnrow[r] = make_float2(mu, __builtin_amdgcn_rsqf(fmaxf((float)var, 0.f) + p.ln_eps));
     }
   }
+  DPTX_ESTAMP(1);
   // rows per load group: 4 (96 registers of loads in flight at most); 2 for the slab epilogue, whose 128 accumulator
   // registers stay live across the slabs
   constexpr int GR_ = SLABS > 1 ? 2 : (ITER < 4 ? ITER : 4);
@@ -485,7 +498,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
           }
         }
       }
+      if (s == 0) DPTX_ESTAMP(2);
     }
+    DPTX_ESTAMP(3);
   };
   using std::integral_constant;
   typedef integral_constant<int, 0> I0;
@@ -499,6 +514,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   else if (has1 && !p.r1_fp32 && !has2 && !p.bias_per_img) body(I1{}, I0{}, I0{}, I0{});  // RCU conv2
   else if (has1 && !p.r1_fp32 && has2 && !p.r2_fp32 && !p.bias_per_img) body(I1{}, I1{}, I0{}, I0{});  // RCU conv2 + path
   else body(IX{}, IX{}, IX{}, I0{});  // patch-embed, readout
+#undef DPTX_ESTAMP
 }
 
 // ------------------------------------------------------------------- direct-to-LDS kernel
@@ -845,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   const bool tr = p.trace != nullptr && blockIdx.x == 0 && lane == 0;
   long long* trp = p.trace + wave * 4 * 64;
 #ifdef DPTX_TRACE   // experiment builds only (build.py DPTX_CXXFLAGS=-DDPTX_TRACE): the stamps cost registers and issue slots
-#define DPTX_STAMP(SLOT) do { if (tr && kt < 64) trp[kt * 4 + (SLOT)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define DPTX_STAMP(SLOT) do { if (tr && kt < 40) trp[kt * 4 + (SLOT)] = (long long)__builtin_readcyclecounter(); } while (0)
   if (tr && wave == 0) { trp[62 * 4 + 0] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 1] = (long long)wall_clock64(); }
 #else
 #define DPTX_STAMP(SLOT) do { } while (0)
@@ -862,6 +878,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       DPTX_PP_ISSUE_A(alo_ptr(0));                                                                                 \
     }                                                                                                              \
   } while (0)
+#ifdef DPTX_TRACE   // tile phases (thread 0 of block 0): row 40 + tile of wave 0's trace block
+  int ti = 0;
+#define DPTX_TSTAMP(SLOT) do { if (tr && wave == 0 && ti < 8) trp[(40 + ti) * 4 + (SLOT)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DPTX_TSTAMP(SLOT) do { } while (0)
+#endif
   DPTX_PP_TILE_SETUP();
   DPTX_PP_PROLOGUE();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -881,6 +903,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // every wave has waited for its own pieces of k-tile 0 (above / inside the previous tile's epilogue) and is done with the
     // epilogue's LDS tile, which the DMA of k-tile 1 overwrites
     __syncthreads();
+    DPTX_TSTAMP(0);
     // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
     // that hipcc resolves with copies: 500 spilled registers)
     PpFrags f0, f1;
@@ -921,6 +944,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading both stages
+    DPTX_TSTAMP(1);
     // next tile of this block: its first k-tile flies into stage 0 under this tile's epilogue, which stages the accumulators
     // through the memory of stage 1 (+ 4.6 KB behind it)
     const int em0 = m0, en0 = n0;
@@ -930,19 +954,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       DPTX_PP_TILE_SETUP();
       DPTX_PP_PROLOGUE();
     }
+    DPTX_TSTAMP(2);
     {
       // opaque copies of the thread coordinates: the epilogue's per-thread addresses are the same for every tile, and hoisted
       // out of the tile loop they would occupy ~40 registers through the k-loop (scratch spills)
       int etid = tid, elr = lr, elh = lh, ewm = wm, ewn = wn;
       asm volatile("" : "+v"(etid), "+v"(elr), "+v"(elh), "+s"(ewm), "+s"(ewn));
-      epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more);
+#ifdef DPTX_TRACE
+      const int trow = ti < 8 ? ti : -1;
+#else
+      const int trow = -1;
+#endif
+      epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
     }
+    DPTX_TSTAMP(3);
+#ifdef DPTX_TRACE
+    ++ti;
+#endif
     if (!more) break;
   }
 #ifdef DPTX_TRACE
   if (tr && wave == 0) { trp[62 * 4 + 2] = (long long)__builtin_readcyclecounter(); trp[62 * 4 + 3] = (long long)wall_clock64(); }
 #endif
 #undef DPTX_STAMP
+#undef DPTX_TSTAMP
 #undef DPTX_PP_PROLOGUE
 #undef DPTX_PP_TILE_SETUP
 #undef DPTX_PP_COORDS
