@@ -197,7 +197,13 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
 // ILV (gemm_ph_kernel, 256x256, 2 x 4 waves): a wave's 4 x 2 MFMA blocks are interleaved over the tile -- row block i of
 // wave row wm sits at tile row (i>>1)*128 + wm*64 + (i&1)*32, column block j of wave column wn at j*128 + wn*32 -- so that
 // the four 128-row half-tiles of a k-tile are needed one phase after the other.
-template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false>
+//
+// WP (wave-private staging; gemm_pp_kernel): every wave transposes its own 32 x 64 block of a slab through its own 9 KB of
+// LDS and writes its own 32 rows x 128 bytes -- no block barrier inside the epilogue, so one wave's LDS round trip runs
+// under another's arithmetic and stores instead of all eight waves marching through write / barrier / read / compute /
+// store in step (a plain bias epilogue took 17.6 k cycles per tile that way for ~4 k cycles of LDS time and ~2.5 k of
+// VALU time: profiles/r03_experiments.md).  Not with row_stats (a record sums 128 columns: two waves).
+template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false, bool WP = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                          int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0, bool dma_in_flight = false,
                                          int trace_row = -1) {
@@ -208,11 +214,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   // m0 + (R >> 5) * row_pitch + (R & 31)
   static_assert(SLABS == 1 || SLABS == TM, "one slab, or one per MFMA row tile");
   static_assert(!ILV || (SLABS == TM && TM == 4 && TN == 2 && BM == 256 && BN == 256), "interleaved mapping: the phased kernel");
-  constexpr int CT_PITCH = BN + 4;  // floats
-  constexpr int CT_ROWS = BM / SLABS;
-  constexpr int NCH = BN / 8;     // 8-column chunks per tile row
-  constexpr int RPP = NT / NCH;   // tile rows per pass
+  static_assert(!WP || (SLABS == TM && TN == 2 && !ILV), "wave-private staging: one 32 x 64 block per wave and slab");
+  constexpr int CT_PITCH = WP ? 72 : BN + 4;  // floats (WP: 4 rows apart = 32 banks apart)
+  constexpr int CT_ROWS = WP ? 32 : BM / SLABS;
+  constexpr int NCH = WP ? 8 : BN / 8;       // 8-column chunks per staged row
+  constexpr int RPP = WP ? 8 : NT / NCH;     // staged rows per pass
   constexpr int ITER = CT_ROWS / RPP;
+  constexpr int WAVES_N = BN / (TN * 32);
   static_assert(CT_ROWS % RPP == 0, "rows per pass must divide the slab");
 #ifdef DPTX_TRACE   // tile-phase stamps of thread 0 of block 0 (tools/gpu/pp_trace.py): rows 48.. of wave 0's trace block
 #define DPTX_ESTAMP(SLOT)                                                                                          \
@@ -225,19 +233,22 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   (void)trace_row;
 #endif
   DPTX_ESTAMP(0);
-  float* ct = (float*)smem;
-  const int cn = tid % NCH;
-  const int rr = tid / NCH;
-  const int n = n0 + cn * 8;
+  float* ct = (float*)smem + (WP ? (wm * WAVES_N + wn) * (32 * CT_PITCH) : 0);
+  const int cn = WP ? tid & 7 : tid % NCH;
+  const int rr = WP ? (tid & 63) >> 3 : tid / NCH;
+  const int n = n0 + (WP ? wn * (TN * 32) : 0) + cn * 8;
 
   if (p.gn_part != nullptr) {
     const int cpg = p.gn_cpg;  // channels per group: 2..32, a power of two
+    const int cpg_sh = __builtin_ctz(cpg);
+    int gn_hw = p.gn_hw;
+    asm volatile("" : "+s"(gn_hw));  // opaque, like c_rpi below: no hoisted divider constants in a tile loop
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // first GEMM row of this wave's i-th 32-row block
       const int mb = m0 + (ILV ? (i >> 1) * 128 + wm * 64 + (i & 1) * 32 : (wm * TM + i) * 32);
-      const int img = mb / p.gn_hw;
-      const int blk = (mb - img * p.gn_hw) >> 5;
+      const int img = mb / gn_hw;
+      const int blk = (mb - img * gn_hw) >> 5;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         float sm = 0.f, sq = 0.f;
@@ -247,7 +258,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         sq += __shfl_xor(sq, 32, 64);
         for (int o = 1; o < cpg; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
         if (lh == 0 && (lr & (cpg - 1)) == 0 && mb < p.M) {
-          const int g = (n0 + (ILV ? j * 128 + wn * 32 : (wn * TN + j) * 32) + lr) / cpg;
+          const int g = (n0 + (ILV ? j * 128 + wn * 32 : (wn * TN + j) * 32) + lr) >> cpg_sh;
           float2* dst = (float2*)p.gn_part + ((long long)img * p.gn_blocks + blk) * 32 + g;
           *dst = make_float2(sm, sq);
         }
@@ -281,7 +292,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   // the 32 (16) threads that own its columns, in every n-tile: per-thread combining cost 64 sixteen-byte loads per thread
   // and tile (+11..14 us per qkv / fc1 launch, profiles/r03_experiments.md).  The table is written before the first
   // __syncthreads() of the slab loop and read after it.
-  float2* lnrow = (float2*)(smem + (size_t)CT_ROWS * CT_PITCH * 4);
+  float2* lnrow = (float2*)(smem + (WP ? (size_t)(NT / 64) * 32 * CT_PITCH * 4 : (size_t)CT_ROWS * CT_PITCH * 4));
   if (p.ln_stats != nullptr) {
     const bool all8 = p.ln_nblk == 8;
     for (int r = tid; r < BM; r += NT) {
@@ -298,6 +309,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
       lnrow[r] = make_float2(mu, __builtin_amdgcn_rsqf(fmaxf((float)var, 0.f) + p.ln_eps));
     }
+    if (WP) __syncthreads();  // the only block barrier of the wave-private epilogue
   }
   DPTX_ESTAMP(1);
   // rows per load group: 4 (96 registers of loads in flight at most); 2 for the slab epilogue, whose 128 accumulator
@@ -336,9 +348,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
 #pragma unroll
       for (int it = 0; it < GR; ++it) {
         const int row = rr + (gi * GR + it) * RPP;
-        int R = SLABS == 1 ? row
-                : ILV      ? (s >> 1) * 128 + (row >> 5) * 64 + (s & 1) * 32 + (row & 31)
-                           : (row >> 5) * (TM * 32) + s * 32 + (row & 31);
+        int R = WP           ? wm * (TM * 32) + s * 32 + row
+                : SLABS == 1 ? row
+                : ILV        ? (s >> 1) * 128 + (row >> 5) * 64 + (s & 1) * 32 + (row & 31)
+                             : (row >> 5) * (TM * 32) + s * 32 + (row & 31);
         if (LNF) ln_R[it] = R;  // tile row: index into the LDS table of (mu, rstd)
         if (row_pitch) R = (R >> 5) * row_pitch + (R & 31);
         int m = m0 + R;
@@ -391,7 +404,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       // ---- (a) the first row group's loads fly while the accumulators are staged
       issue_loads(s, 0);
       // ---- (b) accumulators -> LDS
-      if (s > 0) __syncthreads();  // the previous slab has been read out
+      // WP: the wave's LDS accesses execute in order, the previous slab's reads are ahead of these writes in its queue
+      if (WP) __builtin_amdgcn_wave_barrier();
+      else if (s > 0) __syncthreads();  // the previous slab has been read out
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (SLABS != 1 && i != s) continue;
@@ -399,13 +414,14 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int ml = (SLABS == 1 ? wm * (TM * 32) + i * 32 : wm * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int nl = (ILV ? j * 128 + wn * 32 : wn * (TN * 32) + j * 32) + lr;
+            const int ml = (WP ? 0 : SLABS == 1 ? wm * (TM * 32) + i * 32 : wm * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int nl = (WP ? j * 32 : ILV ? j * 128 + wn * 32 : wn * (TN * 32) + j * 32) + lr;
             ct[ml * CT_PITCH + nl] = acc[i][j][r];
           }
       }
       if (s == 0 && dma_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (WP) __builtin_amdgcn_wave_barrier();
+      else __syncthreads();
       // ---- (c) rows out
 #pragma unroll
       for (int gi = 0; gi < NGR; ++gi) {
@@ -699,22 +715,33 @@ __device__ __forceinline__ void pp_read(PpFrags& f, const char* sa, const char* 
     f.b[j] = *(const u32x4_t*)(sb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
   }
 }
-template <int DT, bool RELU_A>
+// ZC: the tile's very first k-step -- the MFMAs take the constant 0 as their C operand, so the 128 accumulator registers
+// need no zeroing between tiles (128 v_mov per wave and tile in the persistent loop)
+template <int DT, bool RELU_A, bool ZC = false>
 __device__ __forceinline__ void pp_mma(PpFrags& f, f32x16_t (&acc)[4][2]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (RELU_A) f.a[i] = relu8(f.a[i]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], acc[i][j]);
+    for (int j = 0; j < 2; ++j) {
+      if (ZC) {
+        f32x16_t z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], z);
+      } else {
+        acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], acc[i][j]);
+      }
+    }
   }
 }
-// k-steps 0..3 of one k-tile; f0 already holds (or has in flight) k-step 0
-template <int DT, bool RELU_A>
+// k-steps 0..3 of one k-tile; f0 already holds (or has in flight) k-step 0.  ZC: the first k-tile of an output tile
+template <int DT, bool RELU_A, bool ZC = false>
 __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char* sa, const char* sb, int wn, int lr, int lh,
                                             f32x16_t (&acc)[4][2]) {
   pp_read(f1, sa, sb, wn, lr, lh, 1);
   __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A>(f0, acc);
+  pp_mma<DT, RELU_A, ZC>(f0, acc);
   __builtin_amdgcn_sched_barrier(0);
   pp_read(f0, sa, sb, wn, lr, lh, 2);
   __builtin_amdgcn_sched_barrier(0);
@@ -815,8 +842,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
                          (unsigned)(a_iy0[i] * p.Win + a_ix0[i]) * (unsigned)p.a_pix_stride + (unsigned)(sc * 8);  \
       a_off[i] = ok ? e * 2u : 0u;                                                                                 \
     }                                                                                                              \
+    /* byte offsets mod 2^32 (W is < 2^31 bytes: launch_cfg) */                                                    \
     _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                  \
-      w_off[j] = (unsigned)(((long long)(n0 + r0 + 32 * j) * p.ldw + sc * 8) * 2);                                 \
+      w_off[j] = ((unsigned)(n0 + r0 + 32 * j) * (unsigned)p.ldw + (unsigned)(sc * 8)) * 2u;                       \
   } while (0)
   const int w_bytes = (int)((long long)p.N * p.ldw * 2);
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
@@ -867,16 +895,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #define DPTX_STAMP(SLOT) do { } while (0)
   (void)tr; (void)trp;
 #endif
-  // the first k-tile of the tile at (ky, kx, c0) = 0 into stage 0
+  // the first k-tile (tap 0, channel 0) of a tile into stage 0.  Nobody multiplies before all of it has landed, so the
+  // sixteen pieces are split evenly -- each group its own A rows and four of the eight W pieces (the k-loop's split, 12 : 4,
+  // follows from who reads what first); group 0 keeps the W tap state
 #define DPTX_PP_PROLOGUE()                                                                                         \
   do {                                                                                                             \
     ky = kx = c0 = kyw = kxw = c0w = 0;                                                                            \
-    if (wm == 0) {                                                                                                 \
-      DPTX_PP_ISSUE_W(w_ptr(0));                                                                                   \
-      DPTX_PP_ISSUE_A(ahi_ptr(0));                                                                                 \
-    } else {                                                                                                       \
-      DPTX_PP_ISSUE_A(alo_ptr(0));                                                                                 \
+    {                                                                                                              \
+      char* d_ = w_ptr(0) + wq * 1024;                                                                             \
+      const int jb_ = wm == 0 ? 0 : 4;                                                                             \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(d_ + 32 * (jb_ + j) * 128), \
+                                                 16, wm == 0 ? w_off[j] : w_off[4 + j], 0, 0, 0);                  \
     }                                                                                                              \
+    DPTX_PP_NEXT(kyw, kxw, c0w);                                                                                   \
+    if (wm == 0) DPTX_PP_ISSUE_A(ahi_ptr(0));                                                                      \
+    else DPTX_PP_ISSUE_A(alo_ptr(0));                                                                              \
   } while (0)
 #ifdef DPTX_TRACE   // tile phases (thread 0 of block 0): row 40 + tile of wave 0's trace block
   int ti = 0;
@@ -893,13 +927,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     asm volatile("" : "+s"(l));
     DPTX_PP_COORDS();
     DPTX_PP_TILE_SETUP();
-    f32x16_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16_t acc[TM][TN];  // not zeroed: the first k-step's MFMAs take C = 0 (the peeled kt = 0 below)
     // every wave has waited for its own pieces of k-tile 0 (above / inside the previous tile's epilogue) and is done with the
     // epilogue's LDS tile, which the DMA of k-tile 1 overwrites
     __syncthreads();
@@ -907,41 +935,51 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
     // that hipcc resolves with copies: 500 spilled registers)
     PpFrags f0, f1;
+    // one k-tile of group 0 / group 1 (ZC: kt == 0, peeled in front of each loop)
+#define DPTX_PP_G0_ITER(ZC)                                                                                        \
+  do {                                                                                                             \
+    DPTX_STAMP(0);                                                                                                 \
+    /* slot 1: the DMA -- W and A rows 128..255 of tile kt+1 */                                                    \
+    const char* sa = alo_ptr(kt & 1);                                                                              \
+    const char* sb = w_ptr(kt & 1);                                                                                \
+    if (kt + 1 < nk) {                                                                                             \
+      DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));                                                                        \
+      DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));                                                                      \
+    }                                                                                                              \
+    DPTX_STAMP(1);                                                                                                 \
+    asm volatile("s_barrier" ::: "memory");                                                                        \
+    DPTX_STAMP(2);                                                                                                 \
+    pp_read(f0, sa, sb, wn, lr, lh, 0);            /* slot 2 */                                                    \
+    pp_mma_tile<DT, RELU_A, ZC>(f0, f1, sa, sb, wn, lr, lh, acc);                                                  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* what group 1 reads in its next slot has landed */         \
+    DPTX_STAMP(3);                                                                                                 \
+    asm volatile("s_barrier" ::: "memory");                                                                        \
+  } while (0)
+#define DPTX_PP_G1_ITER(ZC)                                                                                        \
+  do {                                                                                                             \
+    DPTX_STAMP(0);                                                                                                 \
+    const char* sa = ahi_ptr(kt & 1);              /* slot 1 */                                                    \
+    const char* sb = w_ptr(kt & 1);                                                                                \
+    pp_read(f0, sa, sb, wn, lr, lh, 0);                                                                            \
+    pp_mma_tile<DT, RELU_A, ZC>(f0, f1, sa, sb, wn, lr, lh, acc);                                                  \
+    /* its DMA of the previous slot 2 (A rows 0..127 of THIS tile) has landed before group 0 reads it in slot 2 */ \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+    DPTX_STAMP(1);                                                                                                 \
+    asm volatile("s_barrier" ::: "memory");                                                                        \
+    DPTX_STAMP(2);                                                                                                 \
+    if (kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   /* slot 2 */                                        \
+    DPTX_STAMP(3);                                                                                                 \
+    asm volatile("s_barrier" ::: "memory");                                                                        \
+  } while (0)
     if (wm == 0) {
-      for (int kt = 0; kt < nk; ++kt) {
-        DPTX_STAMP(0);
-        // slot 1: the DMA -- W and A rows 128..255 of tile kt+1
-        const char* sa = alo_ptr(kt & 1);
-        const char* sb = w_ptr(kt & 1);
-        if (kt + 1 < nk) {
-          DPTX_PP_ISSUE_W(w_ptr((kt + 1) & 1));
-          DPTX_PP_ISSUE_A(ahi_ptr((kt + 1) & 1));
-        }
-        DPTX_STAMP(1);
-        asm volatile("s_barrier" ::: "memory");
-        DPTX_STAMP(2);
-        pp_read(f0, sa, sb, wn, lr, lh, 0);            // slot 2
-        pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what group 1 reads in its next slot has landed
-        DPTX_STAMP(3);
-        asm volatile("s_barrier" ::: "memory");
-      }
+      { const int kt = 0; DPTX_PP_G0_ITER(true); }
+      for (int kt = 1; kt < nk; ++kt) DPTX_PP_G0_ITER(false);
     } else {
-      for (int kt = 0; kt < nk; ++kt) {
-        DPTX_STAMP(0);
-        const char* sa = ahi_ptr(kt & 1);              // slot 1
-        const char* sb = w_ptr(kt & 1);
-        pp_read(f0, sa, sb, wn, lr, lh, 0);
-        pp_mma_tile<DT, RELU_A>(f0, f1, sa, sb, wn, lr, lh, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its DMA of the previous slot 2 (A rows 0..127 of THIS
-        DPTX_STAMP(1);                                    // tile) has landed before group 0 reads it in slot 2
-        asm volatile("s_barrier" ::: "memory");
-        DPTX_STAMP(2);
-        if (kt + 1 < nk) DPTX_PP_ISSUE_A(alo_ptr((kt + 1) & 1));   // slot 2
-        DPTX_STAMP(3);
-        asm volatile("s_barrier" ::: "memory");
-      }
+      { const int kt = 0; DPTX_PP_G1_ITER(true); }
+      for (int kt = 1; kt < nk; ++kt) DPTX_PP_G1_ITER(false);
     }
+#undef DPTX_PP_G0_ITER
+#undef DPTX_PP_G1_ITER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done reading both stages
     DPTX_TSTAMP(1);
@@ -965,7 +1003,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #else
       const int trow = -1;
 #endif
-      epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
+      if (p.row_stats == nullptr)
+        epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS, false, true>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
+      else  // the producer side of the LayerNorm fold reduces 128 columns of a row: block-wide staging
+        epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
     }
     DPTX_TSTAMP(3);
 #ifdef DPTX_TRACE
@@ -1211,7 +1252,9 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       if (per_xcd < 0) { const char* e = getenv("DPTX_PERSIST"); per_xcd = e ? atoi(e) : 32; }
       const int ltot = tiles / 8;
       const int grid = per_xcd > 0 && ltot > per_xcd ? 8 * per_xcd : tiles;
-      constexpr size_t smem_pp = (size_t)256 * 256 + (size_t)64 * (BN + 4) * 4 + (size_t)BM * 8;
+      // (wave-private staging: 8 waves x 32 rows x 72 floats; block-wide staging of the row_stats launches: 64 x 260 floats)
+      constexpr size_t smem_pp = (size_t)256 * 256 + (size_t)8 * 32 * 72 * 4 + (size_t)BM * 8;
+      static_assert((size_t)8 * 32 * 72 * 4 >= (size_t)64 * (BN + 4) * 4, "the block-wide slab fits too");
       static_assert(smem_pp >= smem && smem_pp <= 160 * 1024, "stage 0 + the epilogue's slab and row table");
       auto go = [&](auto k) {
         set_smem_attr(k, smem_pp);
