@@ -1003,7 +1003,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #else
       const int trow = -1;
 #endif
-      if (p.row_stats == nullptr)
+#ifdef DPTX_NO_WP   // A/B builds: block-wide staging everywhere
+      constexpr bool wp_ok = false;
+#else
+      constexpr bool wp_ok = true;
+#endif
+      if (wp_ok && p.row_stats == nullptr)
         epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS, false, true>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
       else  // the producer side of the LayerNorm fold reduces 128 columns of a row: block-wide staging
         epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
