@@ -243,6 +243,26 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float r = __builtin_amdgcn_rcpf(q);  // erfc(z)
   return fmaf(-fabsf(h), r, h + fabsf(h));
 }
+// two elements at a time on 2-vectors: hipcc turns these into v_pk_mul_f32 / v_pk_fma_f32 (the scalar form above becomes
+// v_fmaak_f32 with literal constants, one element per instruction)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
+  const f32x2_t x = {x0, x1};
+  const f32x2_t h = x * 0.5f;
+  const f32x2_t ha = {fabsf(h.x), fabsf(h.y)};
+  const f32x2_t z = ha * 1.41421356237309504880f;  // |x| / sqrt 2
+  f32x2_t q = z * 0.0000430638f + 0.0002765672f;
+  q = q * z + 0.0001520143f;
+  q = q * z + 0.0092705272f;
+  q = q * z + 0.0422820123f;
+  q = q * z + 0.0705230784f;
+  q = q * z + 1.0f;
+  q *= q; q *= q; q *= q; q *= q;
+  const f32x2_t r = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+  const f32x2_t y = (h + ha) - ha * r;
+  x0 = y.x;
+  x1 = y.y;
+}
 
 // Bijective XCD-aware remap of a 1-D block id: blocks that the dispatcher places on one
 // XCD (id % 8) receive a contiguous range of logical work-group ids, so neighbouring tiles

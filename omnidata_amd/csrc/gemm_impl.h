@@ -206,7 +206,9 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
 template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false, bool WP = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                          int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0, bool dma_in_flight = false,
-                                         int trace_row = -1) {
+                                         int trace_row = -1, const char* lds_ln = nullptr) {
+  // lds_ln (persistent gemm_pp_kernel): the (sum, sum of squares) records of the tile's BM rows, 64 bytes per tile row,
+  // already in LDS (DMA'd at the start of the tile's k-loop; rows >= M read as zeros and are masked below)
   // dma_in_flight (persistent gemm_pp_kernel): the caller has LDS-DMA of its next tile outstanding; the epilogue waits for
   // it together with its own first loads, BEFORE its first store (stores count in vmcnt on gfx9: a vmcnt(0) after them
   // would wait for the tile to reach memory)
@@ -300,7 +302,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       if (row_pitch) R = (R >> 5) * row_pitch + (R & 31);
       int m = m0 + R;
       m = m < p.M ? m : m0;
-      const float4* st = (const float4*)(p.ln_stats + (long long)m * 16);
+      const float4* st = lds_ln != nullptr ? (const float4*)(lds_ln + r * 64) : (const float4*)(p.ln_stats + (long long)m * 16);
       const float4 r0 = st[0], r1_ = st[1], r2_ = st[2], r3_ = st[3];
       const float sm = (r0.x + r0.z) + (r1_.x + r1_.z) + ((r2_.x + r2_.z) + (all8 ? r3_.x + r3_.z : 0.f));
       const float sq = (r0.y + r0.w) + (r1_.y + r1_.w) + ((r2_.y + r2_.w) + (all8 ? r3_.y + r3_.w : 0.f));
@@ -457,7 +459,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
           } else if (p.act == 2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 8; e += 2) gelu_erf2(v[e], v[e + 1]);
           }
           if (r1) {
             if (r1f) {
@@ -778,6 +780,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
   constexpr int SLABS = TM;
   constexpr int HALF = 128 * 128;  // bytes of a 128-row operand tile
+  // LDS: [stage 0 | stage 1, re-used by the epilogue: 8 x 32 x 72 floats + the (mu, rstd) row table | statistics records]
+  constexpr int LN_LDS = 4 * HALF + 8 * 32 * 72 * 4 + BM * 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // Thread coordinates.  They are re-derived from an opaque copy of threadIdx at the top of every tile (DPTX_PP_COORDS) so
   // that none of them -- nor anything computed from them -- has to stay in a register across the epilogue, whose slab loop
@@ -932,6 +936,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     // epilogue's LDS tile, which the DMA of k-tile 1 overwrites
     __syncthreads();
     DPTX_TSTAMP(0);
+    // LayerNorm fold, consumer side: the tile's 256 statistics records (64 bytes per row) travel to LDS under the k-loop --
+    // two 16-byte pieces per thread, lane-linear = row-major; read by the epilogue's row table instead of a global load whose
+    // latency nothing covered
+    if (p.ln_stats != nullptr) {
+      const __amdgpu_buffer_rsrc_t rsrcS =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ln_stats), 0, (int)((long long)p.M * 64), 0x00020000);
+      _Pragma("unroll") for (int k = 0; k < 2; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, (__attribute__((address_space(3))) void*)(smem + LN_LDS + (wave * 2 + k) * 1024), 16,
+                                                 (unsigned)m0 * 64u + (unsigned)((wave * 2 + k) * 1024 + lane * 16), 0, 0, 0);
+    }
     // two straight-line loops, one per group (an MFMA under a per-slot branch makes the 128 accumulator registers a phi
     // that hipcc resolves with copies: 500 spilled registers)
     PpFrags f0, f1;
@@ -1009,7 +1023,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
       constexpr bool wp_ok = true;
 #endif
       if (wp_ok && p.row_stats == nullptr)
-        epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS, false, true>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
+        epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS, false, true>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow,
+                                                                  p.ln_stats != nullptr ? smem + LN_LDS : nullptr);
       else  // the producer side of the LayerNorm fold reduces 128 columns of a row: block-wide staging
         epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
     }
@@ -1258,7 +1273,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       const int ltot = tiles / 8;
       const int grid = per_xcd > 0 && ltot > per_xcd ? 8 * per_xcd : tiles;
       // (wave-private staging: 8 waves x 32 rows x 72 floats; block-wide staging of the row_stats launches: 64 x 260 floats)
-      constexpr size_t smem_pp = (size_t)256 * 256 + (size_t)8 * 32 * 72 * 4 + (size_t)BM * 8;
+      constexpr size_t smem_pp = (size_t)256 * 256 + (size_t)8 * 32 * 72 * 4 + (size_t)BM * 8 + (size_t)BM * 64;  // + the statistics records
       static_assert((size_t)8 * 32 * 72 * 4 >= (size_t)64 * (BN + 4) * 4, "the block-wide slab fits too");
       static_assert(smem_pp >= smem && smem_pp <= 160 * 1024, "stage 0 + the epilogue's slab and row table");
       auto go = [&](auto k) {
