@@ -48,12 +48,21 @@ class DPTDepthModel(BaseModel):
     everything with 3 MFMAs (reference-grade, ~1e-5 / ~1e-4).  'bf16' / 'fp16' are single-pass THROUGHPUT modes: ~2x
     faster, but ~6e-2 / ~9e-3 max-abs from the reference on the seeded weights -- NOT within 1e-3; 'fp8' additionally
     runs the decoder convolutions on e4m3 operands.  ``max_batch`` -- arena size (larger batches are chunked).
+
+    ``overflow_fallback`` (default on): the fp16-plane modes ('mixed', 'fp16x3', 'fp16') cannot represent |x| > 65504,
+    and nothing inside the forward clamps.  The parity claims are validated on synthetic weight families only (the
+    published checkpoints cannot be fetched where this was built), so the FIRST batch a set of weights sees is checked:
+    a non-finite result from finite input switches the model to the bf16-plane mode of the same kind ('bf16x3' for the
+    parity modes, 'bf16' for 'fp16' -- bf16 has fp32's range), warns once and recomputes.  One host synchronisation on
+    that first batch, nothing afterwards.
     """
+
+    _FP16_FALLBACK = {"mixed": "bf16x3", "fp16x3": "bf16x3", "fp16": "bf16"}
 
     def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,
                  backbone: str = "vitb_rn50_384", features: int = 256, readout: str = "project",
                  channels_last: bool = False, use_bn: bool = False, dtype: str = "mixed",
-                 max_batch: int = 32, init_seed: int = 0, x3_groups=0):
+                 max_batch: int = 32, init_seed: int = 0, x3_groups=0, overflow_fallback: bool = True):
         super().__init__()
         if backbone not in BACKBONES:
             # blocks.py:42-44: unknown backbones print and assert
@@ -70,6 +79,8 @@ class DPTDepthModel(BaseModel):
         self.channels_last = channels_last  # accepted and, as in the reference (dpt_depth.py:68-69), a no-op
         self.engine_dtype = dtype
         self.x3_groups = x3_groups
+        self.overflow_fallback = bool(overflow_fallback)
+        self._range_checked = None  # (weights version, dtype) whose first batch came back finite
         self.max_batch = max(1, min(int(max_batch), 48))  # engine limit; larger batches are chunked in forward()
         self.max_hw = (384, 384)  # arena is planned for this input size; grows on demand (forward_flex, vit.py:119)
         init = random_state_dict(init_seed, num_channels, backbone=backbone)
@@ -153,6 +164,19 @@ class DPTDepthModel(BaseModel):
             y = torch.empty(B, self.num_channels, H, W, dtype=_io_dtype(x), device=x.device)
             for i in range(0, B, step):
                 eng.forward(x[i:i + step], out=y[i:i + step])
+        tag = (self._weights_version, self.engine_dtype)
+        if self.overflow_fallback and self.engine_dtype in self._FP16_FALLBACK and self._range_checked != tag:
+            if bool(torch.isfinite(y).all()) or not bool(torch.isfinite(x).all()):
+                self._range_checked = tag
+            else:
+                import warnings
+                safe = self._FP16_FALLBACK[self.engine_dtype]
+                warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} produced non-finite values from finite input -- an "
+                              f"activation exceeds the fp16 range (65504) with these weights; switching this model to "
+                              f"dtype={safe!r} (bf16 planes: fp32's range).  Pass overflow_fallback=False to keep the dtype.")
+                self.engine_dtype = safe
+                self.x3_groups = 0
+                return self.forward(x)
         return y.squeeze(dim=1)  # dpt_depth.py:106-107
 
 
