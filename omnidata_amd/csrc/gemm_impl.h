@@ -719,7 +719,10 @@ __device__ __forceinline__ void pp_read(PpFrags& f, const char* sa, const char* 
 }
 // ZC: the tile's very first k-step -- the MFMAs take the constant 0 as their C operand, so the 128 accumulator registers
 // need no zeroing between tiles (128 v_mov per wave and tile in the persistent loop)
-template <int DT, bool RELU_A, bool ZC = false>
+// SWAP: the MFMA takes the W fragment as its A operand and the A fragment as its B operand, i.e. it produces the block
+// transposed -- a lane then holds ONE row of C (lane % 32) and, per block, 16 columns in four groups of four consecutive
+// ones (column 8 g + 4 (lane / 32) + e in register 4 g + e): what epilogue_direct writes out without the LDS round trip.
+template <int DT, bool RELU_A, bool ZC = false, bool SWAP = false>
 __device__ __forceinline__ void pp_mma(PpFrags& f, f32x16_t (&acc)[4][2]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -730,30 +733,111 @@ __device__ __forceinline__ void pp_mma(PpFrags& f, f32x16_t (&acc)[4][2]) {
         f32x16_t z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], z);
+        acc[i][j] = SWAP ? T16<DT>::mfma32(f.b[j], f.a[i], z) : T16<DT>::mfma32(f.a[i], f.b[j], z);
       } else {
-        acc[i][j] = T16<DT>::mfma32(f.a[i], f.b[j], acc[i][j]);
+        acc[i][j] = SWAP ? T16<DT>::mfma32(f.b[j], f.a[i], acc[i][j]) : T16<DT>::mfma32(f.a[i], f.b[j], acc[i][j]);
       }
     }
   }
 }
 // k-steps 0..3 of one k-tile; f0 already holds (or has in flight) k-step 0.  ZC: the first k-tile of an output tile
-template <int DT, bool RELU_A, bool ZC = false>
+template <int DT, bool RELU_A, bool ZC = false, bool SWAP = false>
 __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char* sa, const char* sb, int wn, int lr, int lh,
                                             f32x16_t (&acc)[4][2]) {
   pp_read(f1, sa, sb, wn, lr, lh, 1);
   __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A, ZC>(f0, acc);
+  pp_mma<DT, RELU_A, ZC, SWAP>(f0, acc);
   __builtin_amdgcn_sched_barrier(0);
   pp_read(f0, sa, sb, wn, lr, lh, 2);
   __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A>(f1, acc);
+  pp_mma<DT, RELU_A, false, SWAP>(f1, acc);
   __builtin_amdgcn_sched_barrier(0);
   pp_read(f1, sa, sb, wn, lr, lh, 3);
   __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A>(f0, acc);
+  pp_mma<DT, RELU_A, false, SWAP>(f0, acc);
   __builtin_amdgcn_sched_barrier(0);
-  pp_mma<DT, RELU_A>(f1, acc);
+  pp_mma<DT, RELU_A, false, SWAP>(f1, acc);
+}
+
+// Epilogue of the transposed-accumulator form of gemm_pp_kernel (DIRECT): bias / LayerNorm fold / ReLU / GELU and a
+// 16-bit store straight from the registers.  A lane owns row lane % 32 of each of its four 32-row blocks; the two lanes
+// lane and lane ^ 32 hold interleaved groups of four columns, and one v_permlane32_swap per register pair hands each of
+// them eight CONSECUTIVE columns -- a 16-byte store, 32 bytes contiguous per row and instruction.  No accumulator goes
+// through LDS (the staged epilogue moves 512 KB per tile through it and takes 12-18 k cycles of a 57-72 k-cycle K = 768
+// tile); LDS only holds the tile's 256 bias / column-sum values and the (mu, rstd) row table.
+// Launches it serves (launch_cfg): no residual, no row remap, no per-image bias, no statistics, 16-bit C, one plane.
+template <int DT>
+__device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
+                                                int tid, f32x16_t (&acc)[4][2], bool dma_in_flight, const char* lds_ln) {
+  float* sbias = (float*)smem;          // [256]
+  float* scol = sbias + 256;            // [256] column sums of the folded weight
+  float2* lnrow = (float2*)(scol + 256);  // [256] (mu, rstd)
+  const bool lnf = p.ln_stats != nullptr;
+  if (tid < 256) {
+    sbias[tid] = p.bias != nullptr ? p.bias[n0 + tid] : 0.f;
+    scol[tid] = lnf ? p.ln_colsum[n0 + tid] : 0.f;
+  } else if (lnf) {
+    const int r = tid - 256;
+    const bool all8 = p.ln_nblk == 8;
+    int m = m0 + r;
+    m = m < p.M ? m : m0;
+    const float4* st = lds_ln != nullptr ? (const float4*)(lds_ln + r * 64) : (const float4*)(p.ln_stats + (long long)m * 16);
+    const float4 r0 = st[0], r1_ = st[1], r2_ = st[2], r3_ = st[3];
+    // same association as the staged epilogue's table: the two forms give bit-identical results
+    const float sm = (r0.x + r0.z) + (r1_.x + r1_.z) + ((r2_.x + r2_.z) + (all8 ? r3_.x + r3_.z : 0.f));
+    const float sq = (r0.y + r0.w) + (r1_.y + r1_.w) + ((r2_.y + r2_.w) + (all8 ? r3_.y + r3_.w : 0.f));
+    const float mu = sm * p.ln_inv_dim;
+    const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
+    lnrow[r] = make_float2(mu, __builtin_amdgcn_rsqf(fmaxf((float)var, 0.f) + p.ln_eps));
+  }
+  // the next tile's first k-tile (DMA issued by the caller) lands before this tile's first store is issued: stores count
+  // in vmcnt, a vmcnt(0) after them would wait for the tile to reach memory
+  if (dma_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wm * 128 + i * 32 + lr;
+    const int m = m0 + row;
+    const bool ok = m < p.M;
+    float2 ms = make_float2(0.f, 1.f);
+    if (lnf) ms = lnrow[row];
+    uint16_t* crow = (uint16_t*)p.C + ((long long)p.c_row_off + (ok ? m : m0)) * p.ldc + n0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // lanes 0..31 keep their even group and receive the partner's; lanes 32..63 likewise with the odd group
+          const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * pr + e]),
+                                                              __float_as_uint(acc[i][j][8 * pr + 4 + e]), false, false);
+          v[e] = __uint_as_float(sw.x);
+          v[4 + e] = __uint_as_float(sw.y);
+        }
+        const int col = wn * 64 + j * 32 + 8 * (2 * pr + lh);
+        const float4 b0 = *(const float4*)(sbias + col), b1 = *(const float4*)(sbias + col + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        if (lnf) {
+          const float4 c0 = *(const float4*)(scol + col), c1 = *(const float4*)(scol + col + 4);
+          const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(-ms.x, cc[e], v[e]) * ms.y;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bb[e];
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) gelu_erf2(v[e], v[e + 1]);
+        }
+        if (ok) store8f<DT, 1>(crow + col, 0, v);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------- ping-pong 256x256 kernel
@@ -774,7 +858,9 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 // (Round 2 measured seven variants of this schedule -- third LDS buffer, all DMA on one group, one barrier per k-tile with
 // overlapping MFMA slots, s_setprio, the guide's 8-phase structure, a 256x128 three-stage tile, an LDS-resident conv halo
 // -- all <= 0: profiles/r02_experiments.md; the three that are kernels of their own live in experiments/.)
-template <int DT, bool RELU_A, int PLE = 1>
+// DIRECT: transposed accumulators + epilogue_direct (the launches with a plain epilogue: qkv, fc1, the first convolution of a
+// RCU, layerN_rn, output_conv.0); everything else about the kernel is the same.
+template <int DT, bool RELU_A, int PLE = 1, bool DIRECT = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
@@ -964,7 +1050,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     asm volatile("s_barrier" ::: "memory");                                                                        \
     DPTX_STAMP(2);                                                                                                 \
     pp_read(f0, sa, sb, wn, lr, lh, 0);            /* slot 2 */                                                    \
-    pp_mma_tile<DT, RELU_A, ZC>(f0, f1, sa, sb, wn, lr, lh, acc);                                                  \
+    pp_mma_tile<DT, RELU_A, ZC, DIRECT>(f0, f1, sa, sb, wn, lr, lh, acc);                                          \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* what group 1 reads in its next slot has landed */         \
     DPTX_STAMP(3);                                                                                                 \
     asm volatile("s_barrier" ::: "memory");                                                                        \
@@ -975,7 +1061,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const char* sa = ahi_ptr(kt & 1);              /* slot 1 */                                                    \
     const char* sb = w_ptr(kt & 1);                                                                                \
     pp_read(f0, sa, sb, wn, lr, lh, 0);                                                                            \
-    pp_mma_tile<DT, RELU_A, ZC>(f0, f1, sa, sb, wn, lr, lh, acc);                                                  \
+    pp_mma_tile<DT, RELU_A, ZC, DIRECT>(f0, f1, sa, sb, wn, lr, lh, acc);                                          \
     /* its DMA of the previous slot 2 (A rows 0..127 of THIS tile) has landed before group 0 reads it in slot 2 */ \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
     DPTX_STAMP(1);                                                                                                 \
@@ -1022,7 +1108,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #else
       constexpr bool wp_ok = true;
 #endif
-      if (wp_ok && p.row_stats == nullptr)
+      if constexpr (DIRECT) {
+        (void)trow; (void)wp_ok;
+        epilogue_direct<DT>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, more,
+                            p.ln_stats != nullptr ? smem + LN_LDS : nullptr);
+      } else if (wp_ok && p.row_stats == nullptr)
         epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS, false, true>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow,
                                                                   p.ln_stats != nullptr ? smem + LN_LDS : nullptr);
       else  // the producer side of the LayerNorm fold reduces 128 columns of a row: block-wide staging
@@ -1280,6 +1370,20 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
         set_smem_attr(k, smem_pp);
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem_pp, stream, q);
       };
+      // plain epilogue (bias, LayerNorm fold, activation, one 16-bit plane): the transposed-accumulator form that stores
+      // straight from the registers.  DPTX_DIRECT=0: the staged epilogue everywhere (A/B runs; results agree bit for bit)
+      static int direct_on = -1;
+      if (direct_on < 0) { const char* e = getenv("DPTX_DIRECT"); direct_on = e ? atoi(e) : 1; }
+      const bool direct = direct_on && PLE == 1 && p.R1 == nullptr && p.R2 == nullptr && !p.bias_per_img && p.c_rpi == 0x7fffffff &&
+                          !p.c_fp32 && p.C8 == nullptr && p.C16 == nullptr && p.row_stats == nullptr && p.gn_part == nullptr &&
+                          p.out_scale == 0.f;
+      if constexpr (PLE == 1) {
+        if (direct) {
+          if (p.a_relu) go(gemm_pp_kernel<DT, true, 1, true>);
+          else go(gemm_pp_kernel<DT, false, 1, true>);
+          return hipGetLastError();
+        }
+      }
       if (p.a_relu) go(gemm_pp_kernel<DT, true, PLE>);
       else go(gemm_pp_kernel<DT, false, PLE>);
       return hipGetLastError();
