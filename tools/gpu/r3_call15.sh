@@ -12,9 +12,12 @@ for D in 0 1 0 1; do
   DPTX_DIRECT=$D timeout 300 python tools/gemm_bench.py --only $SH > $O/shapes_d$D.txt 2>&1; echo "direct=$D: $(grep 'TF/s' $O/shapes_d$D.txt | awk '{print $1, $(NF-1)}' | tr '\n' ';')"
 done
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also"
+for D in 0 1; do   # parity numbers of both forms (they must agree digit for digit: same arithmetic per element)
+  DPTX_DIRECT=$D timeout 300 $B > $O/bf16_par_d$D.log 2>&1; echo "direct=$D bf16: $(tail -1 $O/bf16_par_d$D.log | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["value"], d["parity"]["benched_dtype"]["max_abs"], d["parity"]["parity_mode"]["value"], d["parity"]["parity_mode"]["max_abs"])')"
+done
 for rep in 1 2 3; do
   for D in 0 1; do
-    DPTX_DIRECT=$D timeout 300 $B > $O/bf16_d${D}_$rep.log 2>&1; echo "direct=$D bf16: $(tail -1 $O/bf16_d${D}_$rep.log | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["value"], d["parity"]["benched_dtype"]["max_abs"], d["parity"]["parity_mode"]["value"], d["parity"]["parity_mode"]["max_abs"])')"
+    DPTX_DIRECT=$D timeout 300 $B --parity-dtype none > $O/bf16_d${D}_$rep.log 2>&1; echo "direct=$D bf16: $(tail -1 $O/bf16_d${D}_$rep.log | cut -c76-90)"
   done
 done
 for D in 0 1; do
