@@ -290,6 +290,9 @@ int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const fl
 /* Debug: s_memtime stamps of the GEMM k-loop (block 0, lane 0 of each wave; [wave][64 k-tiles][4 phases] int64) into a
  * device buffer of 8*64*4 int64 for every following GEMM launch; NULL switches it off (tools/gpu/gemm_trace.py). */
 int dptx_debug_set_trace(void* dev_buf);
+/* Debug / tests: process-wide switches of the 256x256 GEMM kernel's launch form -- 1: staged epilogue instead of the
+ * register-direct one, 2: one block per tile instead of the persistent tile loop.  Results do not depend on them. */
+int dptx_debug_set_gemm_flags(int32_t flags);
 /* NHWC conv on OCP e4m3 operands (the fp8 dtype's convolution): X8[B,H,W,Cin] and Wt8[Cout][k][k][Cin] are e4m3 bytes
  * (Cin % 128 == 0), fp32 accumulate on the block-scaled fp8 MFMA at unit scale; Y = act(out_scale * conv + bias) (+R) in
  * bf16; Y8 (optional) receives the e4m3 copy of Y (ReLU'd first when q_relu). */

@@ -1691,6 +1691,11 @@ int dptx_debug_set_trace(void* dev_buf) {
   return DPTX_OK;
 }
 
+int dptx_debug_set_gemm_flags(int32_t flags) {
+  gemm_set_debug_flags(flags);
+  return DPTX_OK;
+}
+
 int dptx_op_conv_fp8(const void* X8, const void* Wt8, const float* bias, const void* R, void* Y, void* Y8, int32_t B, int32_t H,
                      int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
                      int32_t Wo, int32_t act, int32_t q_relu, float out_scale, void* stream) {

@@ -18,6 +18,8 @@ void gemm_params_dense(GemmParams& p, int M, int N, int K) {
 
 static long long* g_trace = nullptr;
 void gemm_set_trace(long long* dev_buf) { g_trace = dev_buf; }
+static int g_debug_flags = 0;
+void gemm_set_debug_flags(int flags) { g_debug_flags = flags; }
 static thread_local float g_cu_share = 1.0f, g_cu_share_small = 1.0f;
 void gemm_set_cu_share(float share, float share_small) {
   g_cu_share = share > 0.f && share <= 1.f ? share : 1.0f;
@@ -27,6 +29,7 @@ void gemm_set_cu_share(float share, float share_small) {
 hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   p.trace = g_trace;
+  p.debug_flags = g_debug_flags;
   if (p.cu_share <= 0.f) { p.cu_share = g_cu_share; p.cu_share_small = g_cu_share_small; }
   p.a_rpi_rcp = 1.0f / (float)(p.a_rpi > 0 ? p.a_rpi : 1);
   p.wout_rcp = 1.0f / (float)(p.Wout > 0 ? p.Wout : 1);

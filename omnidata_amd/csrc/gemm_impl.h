@@ -1361,7 +1361,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       static int per_xcd = -1;
       if (per_xcd < 0) { const char* e = getenv("DPTX_PERSIST"); per_xcd = e ? atoi(e) : 32; }
       const int ltot = tiles / 8;
-      const int grid = per_xcd > 0 && ltot > per_xcd ? 8 * per_xcd : tiles;
+      const int grid = per_xcd > 0 && ltot > per_xcd && !(p.debug_flags & 2) ? 8 * per_xcd : tiles;
       // (wave-private staging: 8 waves x 32 rows x 72 floats; block-wide staging of the row_stats launches: 64 x 260 floats)
       constexpr size_t smem_pp = (size_t)256 * 256 + (size_t)8 * 32 * 72 * 4 + (size_t)BM * 8 + (size_t)BM * 64;  // + the statistics records
       static_assert((size_t)8 * 32 * 72 * 4 >= (size_t)64 * (BN + 4) * 4, "the block-wide slab fits too");
@@ -1374,7 +1374,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       // straight from the registers.  DPTX_DIRECT=0: the staged epilogue everywhere (A/B runs; results agree bit for bit)
       static int direct_on = -1;
       if (direct_on < 0) { const char* e = getenv("DPTX_DIRECT"); direct_on = e ? atoi(e) : 1; }
-      const bool direct = direct_on && PLE == 1 && p.R1 == nullptr && p.R2 == nullptr && !p.bias_per_img && p.c_rpi == 0x7fffffff &&
+      const bool direct = direct_on && !(p.debug_flags & 1) && PLE == 1 && p.R1 == nullptr && p.R2 == nullptr && !p.bias_per_img && p.c_rpi == 0x7fffffff &&
                           !p.c_fp32 && p.C8 == nullptr && p.C16 == nullptr && p.row_stats == nullptr && p.gn_part == nullptr &&
                           p.out_scale == 0.f;
       if constexpr (PLE == 1) {

@@ -77,6 +77,7 @@ struct GemmParams {
   int ln_nblk;
   float ln_eps, ln_inv_dim;
   long long* trace;  // debug: s_memtime stamps of block 0 (dptx_debug_set_trace); null in production
+  int debug_flags;   // debug (dptx_debug_set_gemm_flags): 1 = staged epilogue everywhere, 2 = one block per tile
   float a_rpi_rcp, wout_rcp;  // 1 / a_rpi, 1 / Wout (filled in by launch_gemm: row -> (image, y, x) without integer division)
 };
 
@@ -87,6 +88,8 @@ hipError_t launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 // debug: every following GEMM launch stamps s_memtime per k-tile phase for the 8 waves of block 0 into dev_buf
 // ([wave][64 k-tiles][4] int64; null switches it off)
 void gemm_set_trace(long long* dev_buf);
+// debug / tests: 1 = no register-direct epilogue, 2 = no persistent launch (same results either way)
+void gemm_set_debug_flags(int flags);
 // tile selection: the following launches share the chip with (1 / share - 1) concurrent streams of the same forward
 void gemm_set_cu_share(float share, float share_small = 0.f);
 

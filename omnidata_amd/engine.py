@@ -79,6 +79,7 @@ ABI = [
     ("dptx_op_layernorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
     ("dptx_op_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     ("dptx_debug_set_trace", C.c_int, [_vp]),
+    ("dptx_debug_set_gemm_flags", C.c_int, [C.c_int32]),
     ("dptx_op_conv_fp8", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [C.c_float, _vp]),
     ("dptx_op_conv_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 12 + [C.c_float, _vp, _vp]),
     ("dptx_op_upsample2x", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
