@@ -230,36 +230,25 @@ __device__ __forceinline__ float bilerp(float a, float b, float c, float d, floa
 // elements per launch with no MFMA running beside it (~10 us of a 24 us tile with 7.1.26).
 // gelu(x) = x/2 * (1 + erf(x/sqrt 2)) = (h + |h|) - |h| * erfc(|x|/sqrt 2), h = x/2: exact 0 - |h| erfc for x < 0 (no
 // cancellation in the tail); p^16 overflows to inf beyond |x| ~ 24, whose reciprocal is the right limit 0.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float h = 0.5f * x;
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  float q = fmaf(z, 0.0000430638f, 0.0002765672f);
-  q = fmaf(q, z, 0.0001520143f);
-  q = fmaf(q, z, 0.0092705272f);
-  q = fmaf(q, z, 0.0422820123f);
-  q = fmaf(q, z, 0.0705230784f);
-  q = fmaf(q, z, 1.0f);
-  q *= q; q *= q; q *= q; q *= q;
-  const float r = __builtin_amdgcn_rcpf(q);  // erfc(z)
-  return fmaf(-fabsf(h), r, h + fabsf(h));
-}
-// two elements at a time on 2-vectors: hipcc turns these into v_pk_mul_f32 / v_pk_fma_f32 (the scalar form above becomes
-// v_fmaak_f32 with literal constants, one element per instruction)
+// Two elements at a time on 2-vectors: hipcc turns these into v_pk_mul_f32 / v_pk_fma_f32 (a scalar form becomes
+// v_fmaak_f32 with literal constants, one element per instruction).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_erf2(float& x0, float& x1) {
+  // every multiply-add is an explicit fma: the value must not depend on what -ffp-contract does at a call site
+  auto sp = [](float c) { return f32x2_t{c, c}; };
   const f32x2_t x = {x0, x1};
   const f32x2_t h = x * 0.5f;
   const f32x2_t ha = {fabsf(h.x), fabsf(h.y)};
   const f32x2_t z = ha * 1.41421356237309504880f;  // |x| / sqrt 2
-  f32x2_t q = z * 0.0000430638f + 0.0002765672f;
-  q = q * z + 0.0001520143f;
-  q = q * z + 0.0092705272f;
-  q = q * z + 0.0422820123f;
-  q = q * z + 0.0705230784f;
-  q = q * z + 1.0f;
+  f32x2_t q = __builtin_elementwise_fma(z, sp(0.0000430638f), sp(0.0002765672f));
+  q = __builtin_elementwise_fma(q, z, sp(0.0001520143f));
+  q = __builtin_elementwise_fma(q, z, sp(0.0092705272f));
+  q = __builtin_elementwise_fma(q, z, sp(0.0422820123f));
+  q = __builtin_elementwise_fma(q, z, sp(0.0705230784f));
+  q = __builtin_elementwise_fma(q, z, sp(1.0f));
   q *= q; q *= q; q *= q; q *= q;
   const f32x2_t r = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
-  const f32x2_t y = (h + ha) - ha * r;
+  const f32x2_t y = __builtin_elementwise_fma(-ha, r, h + ha);
   x0 = y.x;
   x1 = y.y;
 }

@@ -443,11 +443,14 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             for (int e = 0; e < 8; ++e) v[e] *= osc[e];
           }
           if (LNF) {
+            // y = (acc - mu * colsum) * rstd + bias' as two EXPLICIT fused multiply-adds: every kernel form that can serve a
+            // layer (this one, epilogue_direct, any tile shape) must round identically -- left to -ffp-contract the
+            // compiler fuses "x * rstd + bias" at one call site and not at another (1-ulp differences, which the
+            // batch-invariance test caught)
             const float2 ms = lnrow[ln_R[it]];  // (mu, rstd) of this row: one LDS broadcast read per 32 threads
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaf(-ms.x, ln_c[e], v[e]) * ms.y;
-          }
-          if (bpi) {
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(fmaf(-ms.x, ln_c[e], v[e]), ms.y, bias_c[e]);
+          } else if (bpi) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(bb[it][0][e]); v[4 + e] += __uint_as_float(bb[it][1][e]); }
           } else {
@@ -819,14 +822,15 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem,
         const int col = wn * 64 + j * 32 + 8 * (2 * pr + lh);
         const float4 b0 = *(const float4*)(sbias + col), b1 = *(const float4*)(sbias + col + 4);
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        if (lnf) {
+        if (lnf) {  // the same two explicit fused multiply-adds as the staged epilogue
           const float4 c0 = *(const float4*)(scol + col), c1 = *(const float4*)(scol + col + 4);
           const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaf(-ms.x, cc[e], v[e]) * ms.y;
-        }
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(fmaf(-ms.x, cc[e], v[e]), ms.y, bb[e]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bb[e];
+          for (int e = 0; e < 8; ++e) v[e] += bb[e];
+        }
         if (p.act == 1) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
