@@ -1466,7 +1466,9 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
       const long long t256 = m256 * (p.N / 256), r256 = (t256 + cu1 - 1) / cu1;
       const long long t128 = m128 * (p.N / 128), r128 = (t128 + cu2 - 1) / cu2;
       const double fill256 = (double)t256 / (double)(r256 * cu1), fill128 = (double)t128 / (double)(r128 * cu2);
-      if (t256 >= 200 * sh && fill256 * 1.25 >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4, PLE>(p, stream);
+      static double adv = -1.0;  // DPTX_PP_ADV: the per-tile advantage assumed for the 256x256 kernel (A/B runs)
+      if (adv < 0.0) { const char* e = getenv("DPTX_PP_ADV"); adv = e ? atof(e) : 1.25; }
+      if (t256 >= 200 * sh && fill256 * adv >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4, PLE>(p, stream);
     }
   }
   if constexpr (PL == 2) {

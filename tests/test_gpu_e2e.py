@@ -290,3 +290,27 @@ def test_layernorm_fold_matches_separate_layernorm(dtype):
     print(f"    [{dtype}] out max|d| vs oracle: fold {d0:.3e} separate {d1:.3e}")
     bar = {"bf16": E2E_TOL["bf16"][0], "fp16": E2E_TOL["fp16"][0], "mixed": 1e-3}[dtype]
     assert d0 < bar
+
+
+def test_gemm_launch_forms_agree_bit_for_bit():
+    """The 256x256 GEMM kernel has three launch forms -- register-direct epilogue on transposed accumulators, staged
+    epilogue, one block per tile instead of the persistent tile loop (dptx_debug_set_gemm_flags) -- and a layer's form depends on
+    its shape, i.e. on the batch size: all of them must produce the same bits (explicit fmas in every epilogue; the MFMA is
+    symmetric under operand swap, tools/gpu/probes/mfma_swap.hip).  Whole forward at B = 32, where the ViT GEMMs, the RCU
+    convolutions and the head take that kernel, in bf16 and in the parity mode."""
+    from omnidata_amd.engine import load_library
+    lib = load_library()
+    x = synthetic_input(9, 32, "normal").to(DEV)
+    try:
+        for dtype in ("bf16", "mixed"):
+            model = DPTDepthModel(num_channels=3, dtype=dtype, max_batch=32)
+            model.load_state_dict(random_state_dict(0, 3))
+            model.to(DEV)
+            outs = []
+            for flags in (0, 1, 3):
+                lib.dptx_debug_set_gemm_flags(flags)
+                outs.append(model(x).clone())
+            assert torch.equal(outs[0], outs[1]), dtype   # direct == staged
+            assert torch.equal(outs[1], outs[2]), dtype   # persistent == one block per tile
+    finally:
+        lib.dptx_debug_set_gemm_flags(0)
