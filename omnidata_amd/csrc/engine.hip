@@ -1358,10 +1358,12 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
   const size_t esz = io == DPTX_IO_FP32 ? 4 : 2;  // bytes per element of the caller's buffers
   const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling && !h->calibrating;
   // tile selection of the GEMMs (kernels.h gemm_set_cu_share): a sub-batch run shares the chip with the other streams' runs.
-  // Measured (profiles/r03_experiments.md, two streams): judging the 256x256 rule against 0.7 of the chip -- which moves the
-  // half-batch qkv GEMM (333 tiles) from the 128x128 kernel to the ping-pong kernel -- is worth +1.2 % (bf16) / +1.3 % (mixed);
-  // 0.5 (proj / fc2 at 111 tiles too) and scaled narrow-tile thresholds lose.  DPTX_CU_SHARE / DPTX_CU_SHARE_SMALL override
-  // (1 = tile every launch for the whole chip, as rounds 1-2 did)
+  // Measured (profiles/r03_experiments.md, two streams): the 256x256 rule judged against 1 / streams of the chip (the
+  // half-batch qkv, proj and fc2 GEMMs then take the ping-pong kernel) -- with the lockstep-epilogue kernel of the first half
+  // of round 3 0.7 was the optimum (+1.2 %) and 0.5 lost; with the persistent, register-direct form 0.5 wins on boxes that
+  // are not power-bound (+1.3 ... 2.9 % together with the 1.5 x per-tile advantage in launch_dt) and is neutral on those
+  // that are.  Scaled narrow-tile thresholds lose.  DPTX_CU_SHARE / DPTX_CU_SHARE_SMALL override (1 = tile every launch for
+  // the whole chip, as rounds 1-2 did)
   static float share_env = -1.f, share_small_env = -1.f;
   if (share_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE"); share_env = t ? (float)atof(t) : 0.f; }
   if (share_small_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE_SMALL"); share_small_env = t ? (float)atof(t) : 0.f; }
@@ -1376,7 +1378,7 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
     return rc;
   }
   const int nr = batch < h->n_streams ? batch : h->n_streams;  // sub-batches: the first (batch % nr) get one image more
-  gemm_set_cu_share(share_env > 0.f ? share_env : std::min(1.0f, 1.4f / (float)nr), share_small_env > 0.f ? share_small_env : 1.0f);
+  gemm_set_cu_share(share_env > 0.f ? share_env : 1.0f / (float)nr, share_small_env > 0.f ? share_small_env : 1.0f);
   if (!h->ev_fork) {
     for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
       HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));

@@ -1457,8 +1457,9 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
 #endif
   // 256x256 (8 waves, 1 block/CU; 16-bit modes: the ping-pong kernel): half the DMA issues and 3/4 of the LDS reads per MFMA
   // of the 128x128 tile, but no second block to hide prologue/epilogue and a coarser tail.  Chosen when its estimated
-  // efficiency wins: fill of the last round of CUs (256 slots) x 1.25 (the measured per-tile advantage at K >= 512 with the
-  // pipelined fragment reads, profiles/r02_experiments.md) against the fill of the 128x128 grid (512 slots).  That picks
+  // efficiency wins: fill of the last round of CUs (256 slots) x 1.5 (the per-tile advantage at K >= 512: 1.25 with round 2's
+  // kernel; the persistent tile loop and the register-direct epilogue of round 3 moved the optimum, profiles/r03_experiments.md)
+  // against the fill of the 128x128 grid (512 slots).  That picks
   // it for the ViT GEMMs, patch-embed and the 3x3 convs at 1/4 resolution and keeps 128x128 for the small maps.
   if constexpr (PL == 1) {
     const bool glds_ok = !p.a_fp32 && p.a_bytes > 0 && p.a_bytes < (1ll << 31) && p.M < (1 << 23) && gemm_variant() != 1;
@@ -1467,7 +1468,7 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
       const long long t128 = m128 * (p.N / 128), r128 = (t128 + cu2 - 1) / cu2;
       const double fill256 = (double)t256 / (double)(r256 * cu1), fill128 = (double)t128 / (double)(r128 * cu2);
       static double adv = -1.0;  // DPTX_PP_ADV: the per-tile advantage assumed for the 256x256 kernel (A/B runs)
-      if (adv < 0.0) { const char* e = getenv("DPTX_PP_ADV"); adv = e ? atof(e) : 1.25; }
+      if (adv < 0.0) { const char* e = getenv("DPTX_PP_ADV"); adv = e ? atof(e) : 1.5; }
       if (t256 >= 200 * sh && fill256 * adv >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4, PLE>(p, stream);
     }
   }

@@ -9,12 +9,16 @@ python -c "from omnidata_amd.engine import load_library; print(load_library().dp
 timeout 1500 python -m pytest tests -m gpu -q --tb=short --timeout=900 > $O/pytest_gpu.log 2>&1; echo "exit $?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -4 $O/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 --profile-dump $O/launches.csv > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-300
-for cfg in "--dtype mixed" "--dtype fp16x3" "--dtype fp16" "--task depth" "--task dual" "--task dual --dtype fp8" "--dtype fp8" "--io bf16"; do
+for cfg in "--dtype mixed" "--dtype fp16x3" "--dtype fp16" "--task depth" "--task dual" "--task dual --dtype fp8" "--dtype fp8"; do
   n=$(echo $cfg | tr -d ' -' )
   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also $cfg > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$cfg', d['value'], d['ms_per_step'])"
 done
 DPTX_STREAMS=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also > $O/bench_1stream.log 2>&1; tail -1 $O/bench_1stream.log | cut -c1-120
-DPTX_LN_FOLD=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also > $O/bench_nolnfold.log 2>&1; tail -1 $O/bench_nolnfold.log | cut -c1-120
+# same-box A/B of the round's launch-form changes (results are bit-identical; tests/test_gpu_e2e.py)
+for V in "DPTX_DIRECT=0" "DPTX_PERSIST=0" "DPTX_DIRECT=0 DPTX_PERSIST=0" "DPTX_CU_SHARE=0.7 DPTX_PP_ADV=1.25" "DPTX_DIRECT=1"; do
+  n=$(echo $V | tr -d ' =._')
+  env $V timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also --parity-dtype none > $O/ab_$n.log 2>&1; echo "$V: $(tail -1 $O/ab_$n.log | cut -c76-90)"
+done
 timeout 400 python bench.py --backbone vitl16_384 --task depth --steps 8 --warmup 3 --no-also > $O/bench_vitl16.log 2>&1; tail -1 $O/bench_vitl16.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('vitl16', d['value'], d['roofline']['frac'], d['parity'])"
 timeout 300 python tools/gemm_bench.py --only cal.4096,cal.8192,vit.qkv,vit.proj,vit.fc1,vit.fc2,rcu@96,rcu@48,head.0,l2_rn,l3_rn,s2.c1,s2.c2,s2.c3 --iters 30 > $O/gemm_shapes.txt 2>&1; grep TF/s $O/gemm_shapes.txt | tail -16
 cd /tmp
@@ -24,7 +28,6 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o r -- $B --steps 5 --
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o r -- $B --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o r -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS -d $O/pmc_sq -o r -- $B --steps 2 --warmup 1 > $O/pmc_sq.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU -d $O/pmc_misc -o r -- $B --steps 2 --warmup 1 > $O/pmc_misc.log 2>&1
 unset DPTX_STREAMS
 cd $R
 db() { find $O/$1 -name "*.db" | head -1; }
@@ -32,7 +35,6 @@ python tools/rocprof_summary.py $(db trace) > $O/r03_kernel_trace_stats.txt 2>&1
 python tools/rocprof_summary.py $(db pmc_fetch) --pmc > $O/r03_pmc_fetch_size.txt 2>&1
 python tools/rocprof_summary.py $(db pmc_write) --pmc > $O/r03_pmc_write_size.txt 2>&1
 python tools/rocprof_summary.py $(db pmc_sq) --pmc > $O/r03_pmc_sq.txt 2>&1
-python tools/rocprof_summary.py $(db pmc_misc) --pmc > $O/r03_pmc_misc.txt 2>&1
 python tools/pmc_traffic.py $(db pmc_fetch) $(db pmc_write) 4 130 > $O/r03_pmc_traffic.json 2>&1
 cat $O/r03_pmc_traffic.json | head -12
 head -14 $O/r03_kernel_trace_stats.txt
