@@ -276,18 +276,18 @@ def test_per_layer_policy_api_and_group_policy_flag():
 
 def test_default_model_leaves_fp16_planes_when_they_overflow():
     """fp16 hi planes overflow at 65504 and nothing in the forward clamps.  The decoder is re-parameterised
-    to compute the SAME function with 1e5 x larger internal activations (ReLU is positively homogeneous: layerN_rn weights
-    and every refinenet bias x 1e5, first head conv weight / 1e5): the default model must notice the non-finite result of
+    to compute the SAME function with 1e8 x larger internal activations (ReLU is positively homogeneous: layerN_rn weights
+    and every refinenet bias x 1e8, first head conv weight / 1e8; two fp16 planes still represent 1e5): the default model must notice the non-finite result of
     its first batch, switch to bf16 planes (fp32's range) and still match the fp32 oracle."""
     import warnings
     sd, x, ref, _ = oracle_case("normal", 3, 0, 1)
     big = {k: v.clone() for k, v in sd.items()}
     for k in big:
         if k.startswith("scratch.layer") and k.endswith("_rn.weight"):
-            big[k] *= 1.0e5
+            big[k] *= 1.0e8
         if k.startswith("scratch.refinenet") and k.endswith(".bias"):
-            big[k] *= 1.0e5
-    big["scratch.output_conv.0.weight"] /= 1.0e5
+            big[k] *= 1.0e8
+    big["scratch.output_conv.0.weight"] /= 1.0e8
     model = DPTDepthModel(num_channels=3, max_batch=1).eval()
     model.load_state_dict(big)
     model = model.to(DEV)
@@ -297,7 +297,7 @@ def test_default_model_leaves_fp16_planes_when_they_overflow():
     assert model.engine_dtype == "bf16x3" and any("fp16 range" in str(i.message) for i in w)
     assert torch.isfinite(y).all()
     d = (y - ref).abs().max().item()
-    print(f"    default model on 1e5x activations: fell back to bf16x3, max|d| vs oracle {d:.2e}")
+    print(f"    default model on 1e8x activations: fell back to bf16x3, max|d| vs oracle {d:.2e}")
     assert d < 1e-3
     # a model that is told to keep its dtype returns the non-finite result as it is
     keep = DPTDepthModel(num_channels=3, max_batch=1, overflow_fallback=False).eval()
