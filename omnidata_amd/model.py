@@ -49,15 +49,19 @@ class DPTDepthModel(BaseModel):
     faster, but ~6e-2 / ~9e-3 max-abs from the reference on the seeded weights -- NOT within 1e-3; 'fp8' additionally
     runs the decoder convolutions on e4m3 operands.  ``max_batch`` -- arena size (larger batches are chunked).
 
-    ``overflow_fallback`` (default on): the fp16-plane modes ('mixed', 'fp16x3', 'fp16') cannot represent |x| > 65504,
-    and nothing inside the forward clamps.  The parity claims are validated on synthetic weight families only (the
-    published checkpoints cannot be fetched where this was built), so the FIRST batch a set of weights sees is checked:
-    a non-finite result from finite input switches the model to the bf16-plane mode of the same kind ('bf16x3' for the
-    parity modes, 'bf16' for 'fp16' -- bf16 has fp32's range), warns once and recomputes.  One host synchronisation on
-    that first batch, nothing afterwards.
+    ``overflow_fallback`` (default on): the fp16-plane modes ('mixed', 'fp16x3', 'fp16') cannot represent |x| > 65504
+    (two planes: ~1.3e5), and nothing inside the forward clamps.  The parity claims are validated on synthetic weight
+    families only (the published checkpoints cannot be fetched where this was built), so the FIRST image a set of weights
+    sees is run once more with the stage taps on and every tap (21 stage boundaries) is scanned: a
+    non-finite activation from finite input switches the model to the bf16-plane mode of the same kind ('bf16x3' for the
+    parity modes, 'bf16' for 'fp16' -- bf16 has fp32's range) with a warning.  The taps are read, not the result: the
+    ReLUs of the decoder turn a NaN back into 0 (v_max_f32 returns its non-NaN operand), so an overflow upstream can
+    leave a finite, wrong output.  One extra single-image forward and host copy on that first call, nothing afterwards.
     """
 
     _FP16_FALLBACK = {"mixed": "bf16x3", "fp16x3": "bf16x3", "fp16": "bf16"}
+    _RANGE_TAPS = ("stem", "s0", "s1", "s2", "tok0", "blk0", "blk3", "blk5", "blk8", "blk11", "blk17", "blk23", "l1", "l2", "l3",
+                   "l4", "l1_rn", "l2_rn", "l3_rn", "l4_rn", "p4", "p3", "p2", "p1", "h0", "h1")
 
     def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,
                  backbone: str = "vitb_rn50_384", features: int = 256, readout: str = "project",
@@ -158,26 +162,44 @@ class DPTDepthModel(BaseModel):
             # per-tensor activation scales of the e4m3 copies: measured once, on the first batch this model sees
             # (include/dptx.h dptx_calibrate_fp8; call model.calibrate(x) with a representative batch to choose it)
             eng.calibrate_fp8(x[:step])
+        tag = (self._weights_version, self.engine_dtype)
+        if self.overflow_fallback and self.engine_dtype in self._FP16_FALLBACK and self._range_checked != tag:
+            if self._fp16_range_ok(eng, x[:1]):
+                self._range_checked = tag
+            else:
+                import warnings
+                safe = self._FP16_FALLBACK[self.engine_dtype]
+                warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} produced non-finite activations from finite input -- a "
+                              f"tensor exceeds the fp16 range (65504) with these weights; switching this model to "
+                              f"dtype={safe!r} (bf16 planes: fp32's range).  Pass overflow_fallback=False to keep the dtype.")
+                self.engine_dtype = safe
+                self.x3_groups = 0
+                return self.forward(x)
         if B <= step:
             y = eng.forward(x)
         else:
             y = torch.empty(B, self.num_channels, H, W, dtype=_io_dtype(x), device=x.device)
             for i in range(0, B, step):
                 eng.forward(x[i:i + step], out=y[i:i + step])
-        tag = (self._weights_version, self.engine_dtype)
-        if self.overflow_fallback and self.engine_dtype in self._FP16_FALLBACK and self._range_checked != tag:
-            if bool(torch.isfinite(y).all()) or not bool(torch.isfinite(x).all()):
-                self._range_checked = tag
-            else:
-                import warnings
-                safe = self._FP16_FALLBACK[self.engine_dtype]
-                warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} produced non-finite values from finite input -- an "
-                              f"activation exceeds the fp16 range (65504) with these weights; switching this model to "
-                              f"dtype={safe!r} (bf16 planes: fp32's range).  Pass overflow_fallback=False to keep the dtype.")
-                self.engine_dtype = safe
-                self.x3_groups = 0
-                return self.forward(x)
         return y.squeeze(dim=1)  # dpt_depth.py:106-107
+
+    def _fp16_range_ok(self, eng: Engine, x1: torch.Tensor) -> bool:
+        """One forward of x1 with the stage taps on; False if any tap holds a non-finite value although x1 is finite."""
+        if not bool(torch.isfinite(x1).all()):
+            return True  # the input's problem, not the arithmetic's
+        eng.enable_taps(True)
+        try:
+            eng.forward(x1)
+            for name in self._RANGE_TAPS:
+                try:
+                    t = eng.tap(name)
+                except RuntimeError:
+                    continue  # a tap of the other backbone
+                if not bool(torch.isfinite(t).all()):
+                    return False
+            return True
+        finally:
+            eng.enable_taps(False)
 
 
 class DPTDualTaskModel(nn.Module):

@@ -278,7 +278,7 @@ def test_default_model_leaves_fp16_planes_when_they_overflow():
     """fp16 hi planes overflow at 65504 and nothing in the forward clamps.  The decoder is re-parameterised
     to compute the SAME function with 1e8 x larger internal activations (ReLU is positively homogeneous: layerN_rn weights
     and every refinenet bias x 1e8, first head conv weight / 1e8; two fp16 planes still represent 1e5): the default model must notice the non-finite result of
-    its first batch, switch to bf16 planes (fp32's range) and still match the fp32 oracle."""
+    its first image's activations, switch to bf16 planes (fp32's range) and still match the fp32 oracle."""
     import warnings
     sd, x, ref, _ = oracle_case("normal", 3, 0, 1)
     big = {k: v.clone() for k, v in sd.items()}
@@ -299,8 +299,10 @@ def test_default_model_leaves_fp16_planes_when_they_overflow():
     d = (y - ref).abs().max().item()
     print(f"    default model on 1e8x activations: fell back to bf16x3, max|d| vs oracle {d:.2e}")
     assert d < 1e-3
-    # a model that is told to keep its dtype returns the non-finite result as it is
+    # a model that is told to keep its dtype keeps it -- and is wrong (the decoder's ReLUs turn the NaNs back into zeros:
+    # the RESULT may well be finite, which is why the check reads the stage taps)
     keep = DPTDepthModel(num_channels=3, max_batch=1, overflow_fallback=False).eval()
     keep.load_state_dict(big)
-    y2 = keep.to(DEV)(x.to(DEV))
-    assert keep.engine_dtype == "mixed" and not torch.isfinite(y2).all()
+    y2 = keep.to(DEV)(x.to(DEV)).float().cpu()
+    assert keep.engine_dtype == "mixed"
+    assert not torch.isfinite(y2).all() or (y2 - ref).abs().max().item() > 1e-2
