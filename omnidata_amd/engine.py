@@ -328,6 +328,7 @@ class Engine:
 
     def enable_taps(self, on: bool = True):
         self._check(self.lib.dptx_enable_taps(self.h, int(on)), "enable_taps")
+        self.taps_on = bool(on)
 
     def tap(self, name: str) -> torch.Tensor:
         """Stage activation of the last forward as an fp32 CPU tensor in NCHW ([B,S,768] for tokens; S = 577 at 384x384)."""

@@ -187,6 +187,7 @@ class DPTDepthModel(BaseModel):
         """One forward of x1 with the stage taps on; False if any tap holds a non-finite value although x1 is finite."""
         if not bool(torch.isfinite(x1).all()):
             return True  # the input's problem, not the arithmetic's
+        was_on = getattr(eng, "taps_on", False)  # a caller who records taps keeps doing so
         eng.enable_taps(True)
         try:
             eng.forward(x1)
@@ -199,7 +200,7 @@ class DPTDepthModel(BaseModel):
                     return False
             return True
         finally:
-            eng.enable_taps(False)
+            eng.enable_taps(was_on)
 
 
 class DPTDualTaskModel(nn.Module):
