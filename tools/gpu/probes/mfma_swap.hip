@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/gpu/probes/mfma_swap tools/gpu/probes/mfma_swap.hip (the executable is git-ignored).
 // Is v_mfma_f32_32x32x16_bf16 bit-symmetric under swapping its operands?  D = A B with A 32x16, B 16x32; the swapped call
 // computes D' = B^T A^T = D^T from the SAME registers (a lane's fragment is row (lane % 32), k = 8 (lane / 32) .. +7 of its
 // matrix either way).  Compares D'[n][m] with D[m][n] bit for bit over random operands with a wide exponent spread.
