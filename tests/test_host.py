@@ -214,3 +214,93 @@ def test_config_validation_and_arena_scaling():
         e = Engine(num_channels=3, max_batch=7, device_id=None, streams=ns)
         one = Engine(num_channels=3, max_batch=7, device_id=None, streams=1)
         assert e.workspace_bytes <= one.workspace_bytes * 1.35
+
+
+class _FakeCudaTensor(torch.Tensor):
+    """A CPU tensor that claims to live on the GPU: lets the host-side control flow of DPTDepthModel.forward run here."""
+    @property
+    def is_cuda(self):
+        return True
+
+
+class _StubEngine:
+    """Stands in for omnidata_amd.engine.Engine: records calls; its stage taps are non-finite in the fp16-plane dtypes."""
+    def __init__(self, dtype, overflow):
+        self.dtype, self.overflow, self.taps_on = dtype, overflow, False
+        self.calls = []
+
+    def enable_taps(self, on=True):
+        self.taps_on = bool(on)
+        self.calls.append(("taps", bool(on)))
+
+    def forward(self, x, out=None):
+        self.calls.append(("forward", int(x.shape[0]), self.taps_on))
+        y = torch.zeros(x.shape[0], 3, x.shape[2], x.shape[3])
+        if out is not None:
+            out.copy_(y)
+        return y
+
+    def tap(self, name):
+        if name in ("blk17", "blk23", "l1", "l2"):
+            raise RuntimeError("unknown or unavailable tap")   # taps of the other backbone
+        t = torch.ones(1, 4, 2, 2)
+        if self.overflow and self.dtype in ("mixed", "fp16x3", "fp16") and name == "l2_rn":
+            t[0, 0, 0, 0] = float("nan")
+        return t
+
+    def close(self):
+        pass
+
+
+def _stubbed_model(monkeypatch, dtype, overflow, **kw):
+    model = DPTDepthModel(num_channels=3, dtype=dtype, max_batch=4, **kw)
+    engines = []
+
+    def get_engine(device):
+        if not engines or engines[-1].dtype != model.engine_dtype:
+            engines.append(_StubEngine(model.engine_dtype, overflow))
+        return engines[-1]
+    monkeypatch.setattr(model, "_get_engine", get_engine)
+    return model, engines
+
+
+def test_fp16_overflow_fallback_control_flow(monkeypatch):
+    """Host logic of DPTDepthModel's fp16 range check (the GPU test test_default_model_leaves_fp16_planes_when_they_overflow
+    exercises it on real overflow): first image with taps on, fallback dtype per mode, one check per set of weights, the
+    caller's tap recording restored, no check for the bf16-plane dtypes, for non-finite input, or when switched off."""
+    x = torch.rand(3, 3, 64, 64).as_subclass(_FakeCudaTensor)
+    # healthy weights: one single-image forward with taps, then the real one; the second call does not check again
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=False)
+    model(x)
+    assert engines[0].calls == [("taps", True), ("forward", 1, True), ("taps", False), ("forward", 3, False)]
+    model(x)
+    assert engines[0].calls[4:] == [("forward", 3, False)] and model.engine_dtype == "mixed"
+    # new weights: checked again
+    model._weights_version += 1
+    model(x)
+    assert ("forward", 1, True) in engines[0].calls[5:]
+    # overflow: warning, bf16 planes of the same kind, result computed by the new engine
+    for dtype, safe in (("mixed", "bf16x3"), ("fp16x3", "bf16x3"), ("fp16", "bf16")):
+        model, engines = _stubbed_model(monkeypatch, dtype, overflow=True)
+        with pytest.warns(UserWarning, match="fp16 range"):
+            model(x)
+        assert model.engine_dtype == safe and len(engines) == 2
+        assert engines[1].calls == [("forward", 3, False)]          # no check in the bf16-plane dtype
+        assert ("forward", 3, False) not in engines[0].calls        # the overflowing engine never produced the result
+    # a caller who records taps keeps recording
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=False)
+    model._get_engine(None).enable_taps(True)
+    model(x)
+    assert engines[0].taps_on and engines[0].calls[-1] == ("forward", 3, True)
+    # switched off / dtype without fp16 planes / non-finite input: no check, no fallback
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=True, overflow_fallback=False)
+    model(x)
+    assert model.engine_dtype == "mixed" and engines[0].calls == [("forward", 3, False)]
+    model, engines = _stubbed_model(monkeypatch, "bf16", overflow=True)
+    model(x)
+    assert engines[0].calls == [("forward", 3, False)]
+    bad = x.clone()
+    bad[0, 0, 0, 0] = float("inf")
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=True)
+    model(bad.as_subclass(_FakeCudaTensor))
+    assert model.engine_dtype == "mixed" and ("forward", 3, False) in engines[0].calls
