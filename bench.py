@@ -303,7 +303,10 @@ def main():
                                    + ("(backbone vitl16_384: SURVEY.md 8f row 3, not a BASELINE.json configuration)" if large else
                                       f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])"), "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"replicas x{world} (no collective in the loop)",
-                       "schedule": "each forward = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)"},
+                       "schedule": "each forward = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)",
+                       # A/B switches of the library that were set in this process's environment: none
+                       # in a default run -- a stray one would otherwise change the kernels under the number unseen
+                       "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DPTX_")}},
             "e2e_mfma_frac": round(e2e_tflops / (PEAK_TFLOPS * world), 4) if args.dtype in ("bf16", "fp16") else None,
             "e2e_tflops_algorithmic": round(e2e_tflops, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "also": also, "kernel_breakdown": breakdown,
