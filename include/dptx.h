@@ -104,7 +104,8 @@ typedef struct dptx_config {
  * GEMMs multiply (what the reference itself does under model.half() / .bfloat16()): the proj / fc2 epilogues move 4 instead
  * of 10 bytes per element; the deviation from the fp32 forward grows by 1-5 % of itself (profiles/r03_experiments.md).
  * MIXED and the 3-MFMA dtypes always keep the fp32 stream. */
-enum { DPTX_FLAG_NO_LN_FOLD = 1, DPTX_FLAG_GROUP_POLICY = 2, DPTX_FLAG_FP32_STREAM = 4 };
+/* NO_RANGE_CHECK: skip the per-forward range scan of the fp16-plane dtypes (see dptx_range_status). */
+enum { DPTX_FLAG_NO_LN_FOLD = 1, DPTX_FLAG_GROUP_POLICY = 2, DPTX_FLAG_FP32_STREAM = 4, DPTX_FLAG_NO_RANGE_CHECK = 8 };
 
 /* Fills *cfg with the reference defaults: C=3, max_batch=32, dtype MIXED (the mode that matches the reference's fp32
  * forward within 1e-3; DPTX_DTYPE_BF16 is the ~1.6x faster throughput mode that does not), device 0, non_negative=1,
@@ -201,6 +202,16 @@ int dptx_calibrate_fp8(dptx_handle h, const void* x_dev, int32_t x_dtype, void* 
 int dptx_fp8_get_calibration(dptx_handle h, float* scales, float* amax, int32_t capacity);
 int dptx_fp8_set_calibration(dptx_handle h, const float* scales, int32_t n);
 
+/* Range check of the fp16-plane dtypes (FP16, FP16X3, MIXED): fp16 planes cannot hold |x| > 65504 and nothing in the forward
+ * clamps.  Every forward of such a handle scans the first head convolution's output -- the tensor that every decoder path
+ * and, through them, the ViT blocks reach by residual additions -- for Inf / NaN (one 9.4 MB/image read, ~0.3 % of the
+ * forward) and ORs the finding into a STICKY device flag.  dptx_range_status waits for `stream`, stores the flag in
+ * *nonfinite (0 / 1), and clears it when reset != 0.  The check reads the activations, not the result: ReLUs behind the
+ * scanned tensor turn a NaN into 0, so an overflow can leave a finite, wrong output.  Always 0 for the bf16-plane dtypes
+ * (fp32's exponent range) and with DPTX_FLAG_NO_RANGE_CHECK.  omnidata_amd.model reads it after the first forward of a
+ * set of weights and periodically afterwards, and falls back to bf16 planes (BF16X3 / BF16) when it is set. */
+int dptx_range_status(dptx_handle h, int32_t* nonfinite, int32_t reset, void* stream);
+
 /* Debug hook for stage-level parity (SURVEY.md A.1 tap names: "stem","s0","s1","s2","tok0",
  * "blk0".."blk11","l3","l4","l1_rn".."l4_rn","p4","p3","p2","p1","h0","h1").  Copies the
  * stage activation of the LAST forward, converted to fp32 in the engine's internal layout
@@ -290,6 +301,19 @@ int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const fl
 /* Debug: s_memtime stamps of the GEMM k-loop (block 0, lane 0 of each wave; [wave][64 k-tiles][4 phases] int64) into a
  * device buffer of 8*64*4 int64 for every following GEMM launch; NULL switches it off (tools/gpu/gemm_trace.py). */
 int dptx_debug_set_trace(void* dev_buf);
+/* Debug / tests (tests/test_gpu_poison.py): the activation arena of a handle.  A forward must not read an arena byte it
+ * has not written itself -- dptx_debug_arena_fill sets every byte of the arena (all planes) to byte_value (0xFF: NaN in
+ * every element type used) after a device synchronisation; the next forward's result must not change.
+ * dptx_debug_arena_read copies a byte range to the host; dptx_debug_arena_layout writes "key value" / "buf name off bytes
+ * off2" lines (off: whole-batch plan, off2: inside a sub-batch region of the multi-stream plan) and returns the size needed. */
+int dptx_debug_arena_fill(dptx_handle h, int32_t byte_value);
+int dptx_debug_arena_read(dptx_handle h, void* dst_host, size_t offset, size_t bytes);
+int dptx_debug_arena_layout(dptx_handle h, char* dst, size_t capacity);
+/* One 64-bit word sum per arena buffer, sub-batch region and plane of the layout the LAST forward used, computed on `stream`
+ * behind that forward: out_dev[(plane * regions + region) * nbuf + buf] (uint64, device memory), buffers in the order of
+ * dptx_debug_arena_layout.  Returns the number of sums; with out_dev = NULL the capacity needed.  Two forwards of one input
+ * must give the same vector; the first entry that differs names the tensor (tools/gpu/r4_hunt.py). */
+int dptx_debug_arena_checksums(dptx_handle h, void* out_dev, int32_t capacity, void* stream);
 /* Debug / tests: process-wide switches of the 256x256 GEMM kernel's launch form -- 1: staged epilogue instead of the
  * register-direct one, 2: one block per tile instead of the persistent tile loop.  Results do not depend on them. */
 int dptx_debug_set_gemm_flags(int32_t flags);

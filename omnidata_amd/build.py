@@ -46,13 +46,26 @@ def built_hash(suffix: str = "") -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """DPTX_CXXFLAGS / DPTX_LIB_SUFFIX (experiments): extra compiler flags and a suffix for the object directory and the
-    library name (libdptx<suffix>.so), so that kernel variants can be built side by side; engine.py loads $DPTX_LIB."""
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("DPTX_CXXFLAGS", "").split()
+    library name (libdptx<suffix>.so), so that kernel variants can be built side by side; engine.py loads $DPTX_LIB.
+    One builder at a time per object directory (flock on <objdir>/.lock: ranks launched together by torchrun with a stale
+    tree queue up, and all but the first find everything up to date); the library is linked to a temporary name and renamed
+    into place, so a concurrent dlopen sees the old file or the new one, never a half-written one."""
+    import fcntl
     suffix = os.environ.get("DPTX_LIB_SUFFIX", "")
-    LIB = os.path.join(HERE, f"libdptx{suffix}.so")
     objdir = os.path.join(CSRC, "build" + suffix)
     os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, suffix, objdir)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool, suffix: str, objdir: str) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("DPTX_CXXFLAGS", "").split()
+    LIB = os.path.join(HERE, f"libdptx{suffix}.so")
     hdrs = [os.path.join(CSRC, h) for h in HEADERS + EXPERIMENT_HEADERS]
     src_hash = source_hash(extra)
     hash_file = os.path.join(objdir, "engine.srchash")  # engine.o embeds the hash: rebuilt whenever any source changed
@@ -76,10 +89,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
     if force or procs or not _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        tmp = f"{LIB}.tmp{os.getpid()}"
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError(f"link failed:\n{r.stdout}")
+        os.replace(tmp, LIB)
     with open(hash_file, "w") as f:
         f.write(src_hash + "\n")
     return LIB

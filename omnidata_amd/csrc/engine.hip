@@ -288,6 +288,20 @@ size_t packed_entry_bytes(const Spec& s) {
   }
 }
 
+// The packed blob starts with a 256-byte header that names the layout it was packed for: ranks (dptx_import_packed_device) and
+// the on-disk cache refuse a blob whose packing differs from what this handle would produce itself -- e.g. a rank whose
+// environment switched the LayerNorm fold off would otherwise multiply folded qkv / fc1 weights as if they were plain.
+constexpr size_t BLOB_HEADER = 256;
+struct BlobHeader {
+  char magic[8];          // "DPTXBLOB"
+  uint32_t version;       // layout version of this header / of the packing code
+  int32_t dtype, backbone, dual_task, num_channels, ln_fold, ws_form;
+  float ws_eps;
+  uint64_t packed_single, packed_bytes;
+};
+static_assert(sizeof(BlobHeader) <= BLOB_HEADER, "header fits its slot");
+constexpr uint32_t BLOB_VERSION = 4;
+
 struct Buf {  // arena slice: `off` in the whole-batch plan, `off2` in the half-batch plan (two sub-batches on two streams)
   size_t off = 0, bytes = 0, off2 = 0;
 };
@@ -371,6 +385,12 @@ struct dptx_engine {
   int n_q8 = 0;                  // slots used by the last forward
   bool calibrating = false, calibrated = false;
   unsigned* d_amax = nullptr;    // [MAX_Q8] float bits (calibration forwards only)
+  // range check of the fp16-plane dtypes (include/dptx.h dptx_range_status): sticky device flag, set by a scan of H0
+  unsigned* d_range = nullptr;
+  bool range_check() const {
+    return (cfg.dtype == DPTX_DTYPE_FP16 || cfg.dtype == DPTX_DTYPE_FP16X3 || cfg.dtype == DPTX_DTYPE_MIXED) &&
+           !(cfg.flags & DPTX_FLAG_NO_RANGE_CHECK);
+  }
   void* q8(const void* p) const { return d_arena + arena_single + ((const char*)p - d_arena) / 2; }  // e4m3 copy of an arena tensor
   // fused head tail (head.hip): single-plane head, no stage taps wanted; DPTX_HEAD_FUSED=0 keeps the three launches
   bool head_fused(bool conv2_x3) const {
@@ -383,6 +403,7 @@ struct dptx_engine {
   int64_t launches = 0;
   double exec_macs = 0.0;
   int last_batch = 0;
+  int last_regions = 1;  // sub-batch regions the last forward used (1: the whole-batch plan)
   // optional per-launch timing (one event after every launch; kernels are serialized on the stream)
   bool profiling = false;
   std::vector<hipEvent_t> events;
@@ -411,6 +432,16 @@ struct dptx_engine {
   }
   const void* w(const std::string& key) const { return d_blob + packed_off.at(key); }
   const float* f(const std::string& key) const { return (const float*)(d_blob + packed_off.at(key)); }
+  BlobHeader blob_header() const {
+    BlobHeader hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, "DPTXBLOB", 8);
+    hd.version = BLOB_VERSION;
+    hd.dtype = cfg.dtype; hd.backbone = backbone; hd.dual_task = cfg.dual_task; hd.num_channels = cfg.num_channels;
+    hd.ln_fold = ln_fold ? 1 : 0; hd.ws_form = cfg.ws_form; hd.ws_eps = cfg.ws_eps;
+    hd.packed_single = packed_single; hd.packed_bytes = packed_bytes;
+    return hd;
+  }
 };
 
 namespace {
@@ -506,6 +537,10 @@ int pack_host(dptx_engine* e) {
     if (s.role != R_UNUSED && s.role != R_DERIVED && !e->staged.count(s.key)) missing += (missing.empty() ? "" : ", ") + s.key;
   if (!missing.empty()) return e->fail(DPTX_E_KEY, "missing tensors (strict load): " + missing);
   e->host_blob.assign(e->packed_bytes, 0);
+  {
+    const BlobHeader hd = e->blob_header();
+    memcpy(e->host_blob.data(), &hd, sizeof hd);
+  }
   const bool bf = e->bf16_storage();
   const bool x3 = e->two_planes() && !e->fp8();
   const size_t lo_elems = e->packed_single / 2;  // uint16 distance hi -> lo plane
@@ -1094,6 +1129,11 @@ int Run::forward(const void* x, void* y, void* y2) {
   conv(path, h2, w2, FEAT, oc + "0.weight", 3, 1, 1, 1, h2, w2, 128, A(E->H0), E->f(oc + "0.bias"), 0, 0, nullptr, nullptr, nullptr, 0,
        lo_of(conv2_x3));
   tap((pre + "h0").c_str(), A(E->H0), h2, w2, 128);
+  // fp16-plane dtypes: did anything upstream leave the fp16 range?  (one pass over the hi plane of H0: every decoder path and,
+  // through them, the ViT blocks reach it by residual adds; the ResNetV2 stages cannot overflow -- standardised weights and
+  // a GroupNorm behind every convolution bound them whatever the checkpoint)
+  if (E->range_check() && E->d_range)
+    chk(launch_nonfinite_scan(mx ? MODE_FP16 : dt, A(E->H0), (size_t)B * h2 * w2 * 128, E->d_range, st), "range.scan");
   if (E->head_fused(conv2_x3)) {
     // x2 upsample + conv 128->32 + ReLU + conv 1x1 + ReLU in one launch (head.hip): the 37.7 MB/image up-sampled map
     // and the 32-channel map never reach memory.  Not with a 3-MFMA conv2, and not while stage taps are recorded ("h1").
@@ -1168,7 +1208,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_FP8 || (cfg->ws_form != 0 && cfg->ws_form != 1) ||
-      (cfg->flags & ~(DPTX_FLAG_NO_LN_FOLD | DPTX_FLAG_GROUP_POLICY | DPTX_FLAG_FP32_STREAM)) || cfg->reserved != 0)
+      (cfg->flags & ~(DPTX_FLAG_NO_LN_FOLD | DPTX_FLAG_GROUP_POLICY | DPTX_FLAG_FP32_STREAM | DPTX_FLAG_NO_RANGE_CHECK)) ||
+      cfg->reserved != 0)
     return DPTX_E_INVALID;
   int x3_groups = 0;
   if (cfg->dtype == DPTX_DTYPE_MIXED) {
@@ -1216,7 +1257,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   e->max_w = max_w;
   e->tok_tap_stride = (size_t)cfg->max_batch * ((size_t)max_h * max_w / 256 + 1) * (size_t)e->dv;
   e->spec = build_spec(cfg->num_channels, cfg->dual_task != 0, e->backbone);
-  size_t off = 0;
+  size_t off = BLOB_HEADER;  // the blob's layout tag (BlobHeader)
   for (size_t i = 0; i < e->spec.size(); ++i) {
     e->spec_index[e->spec[i].key] = i;
     const size_t b = packed_entry_bytes(e->spec[i]);
@@ -1249,6 +1290,7 @@ void dptx_destroy(dptx_handle h) {
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
     if (h->d_amax) (void)hipFree(h->d_amax);
+    if (h->d_range) (void)hipFree(h->d_range);
     for (auto ev : h->events) (void)hipEventDestroy(ev);
     for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
       if (h->sub_stream[r]) (void)hipStreamDestroy(h->sub_stream[r]);
@@ -1281,6 +1323,10 @@ static int ensure_device_memory(dptx_handle h) {
   HIPCHK(h, guard.err);
   if (!h->d_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, h->packed_bytes));
   if (!h->d_arena) HIPCHK(h, hipMalloc((void**)&h->d_arena, h->arena_bytes));
+  if (!h->d_range) {
+    HIPCHK(h, hipMalloc((void**)&h->d_range, 256));
+    HIPCHK(h, hipMemset(h->d_range, 0, 256));
+  }
   return DPTX_OK;
 }
 
@@ -1328,6 +1374,22 @@ int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, 
   if (r != DPTX_OK) return r;
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
+  {
+    // the blob's layout tag must be the one this handle packs itself (dtype, backbone, LayerNorm fold, weight-std form ...)
+    BlobHeader got;
+    HIPCHK(h, hipMemcpyAsync(&got, src_dev, sizeof got, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    const BlobHeader want = h->blob_header();
+    if (memcmp(&got, &want, sizeof got) != 0) {
+      char msg[320];
+      snprintf(msg, sizeof msg,
+               "packed blob was packed for another layout: magic %.8s version %u dtype %d backbone %d dual %d channels %d ln_fold %d "
+               "ws_form %d (this handle: version %u dtype %d backbone %d dual %d channels %d ln_fold %d ws_form %d)",
+               got.magic, got.version, got.dtype, got.backbone, got.dual_task, got.num_channels, got.ln_fold, got.ws_form,
+               want.version, want.dtype, want.backbone, want.dual_task, want.num_channels, want.ln_fold, want.ws_form);
+      return h->fail(DPTX_E_INVALID, msg);
+    }
+  }
   HIPCHK(h, hipMemcpyAsync(h->d_blob, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   h->device_ready = true;
   return DPTX_OK;
@@ -1367,6 +1429,8 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
   static float share_env = -1.f, share_small_env = -1.f;
   if (share_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE"); share_env = t ? (float)atof(t) : 0.f; }
   if (share_small_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE_SMALL"); share_small_env = t ? (float)atof(t) : 0.f; }
+  // whatever path leaves this function (HIPCHK returns included), the thread's tile-selection state is back at "whole chip"
+  struct ShareReset { ~ShareReset() { gemm_set_cu_share(1.0f); } } share_reset;
   if (!split) {
     gemm_set_cu_share(1.0f);
     Run run{h, batch, stream, h->cfg.dtype, height, width, io};
@@ -1375,6 +1439,7 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
     h->exec_macs = run.exec_macs;
     for (int c = 0; c < 4; ++c) h->cat_macs[c] = run.cat_macs[c];
     h->last_batch = batch;
+    h->last_regions = 1;
     return rc;
   }
   const int nr = batch < h->n_streams ? batch : h->n_streams;  // sub-batches: the first (batch % nr) get one image more
@@ -1413,6 +1478,7 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
   h->taps.clear();  // stage taps describe whole-batch runs only (dptx_enable_taps makes the forward single-pass)
   h->launches = launches;
   h->last_batch = batch;
+  h->last_regions = nr;
   return rc;
 }
 
@@ -1526,6 +1592,21 @@ int dptx_fp8_set_calibration(dptx_handle h, const float* scales, int32_t n) {
     h->act_scale[i] = scales[i];
   }
   h->calibrated = true;
+  return DPTX_OK;
+}
+
+int dptx_range_status(dptx_handle h, int32_t* nonfinite, int32_t reset, void* stream) {
+  if (!h || !nonfinite) return DPTX_E_INVALID;
+  *nonfinite = 0;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
+  if (!h->range_check() || !h->d_range) return DPTX_OK;  // bf16-plane dtypes have fp32's range: nothing to report
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
+  unsigned v = 0;
+  HIPCHK(h, hipMemcpyAsync(&v, h->d_range, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (reset) HIPCHK(h, hipMemsetAsync(h->d_range, 0, sizeof v, (hipStream_t)stream));
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  *nonfinite = v != 0;
   return DPTX_OK;
 }
 
@@ -1686,6 +1767,93 @@ int dptx_op_groupnorm(int32_t dtype, const void* X, const float* gamma, const fl
   g.X = X; g.Y = Y; g.gamma = gamma; g.beta = beta; g.partial = (float*)scratch_f32; g.R = R;
   g.B = B; g.HW = HW; g.C = C; g.relu = relu; g.eps = eps;
   return launch_gn_apply(dtype, g, g_op_planes, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+// ---- arena debugging (tests/test_gpu_poison.py): a forward must not read an arena byte it did not write itself
+int dptx_debug_arena_fill(dptx_handle h, int32_t byte_value) {
+  if (!h) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
+  if (!h->d_arena) return h->fail(DPTX_E_INVALID, "no arena yet (weights not finalized / imported)");
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemset(h->d_arena, byte_value & 0xff, h->arena_bytes));
+  HIPCHK(h, hipDeviceSynchronize());
+  return DPTX_OK;
+}
+
+int dptx_debug_arena_read(dptx_handle h, void* dst_host, size_t offset, size_t bytes) {
+  if (!h || !dst_host) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
+  if (!h->d_arena || offset > h->arena_bytes || bytes > h->arena_bytes - offset) return h->fail(DPTX_E_INVALID, "arena range");
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(dst_host, h->d_arena + offset, bytes, hipMemcpyDeviceToHost));
+  return DPTX_OK;
+}
+
+static std::vector<std::pair<const char*, const Buf*>> arena_buf_list(dptx_handle h) {
+  return {{"sraw", &h->sraw}, {"stem", &h->stem}, {"S0", &h->S[0]}, {"S1", &h->S[1]}, {"S2", &h->S[2]}, {"T1", &h->T1}, {"T2", &h->T2},
+          {"PA", &h->PA}, {"PB", &h->PB}, {"DS", &h->DS}, {"part0", &h->part[0]}, {"part1", &h->part[1]}, {"part2", &h->part[2]},
+          {"part3", &h->part[3]}, {"X", &h->X}, {"lnst", &h->lnst}, {"Hn", &h->Hn}, {"QKV", &h->QKV}, {"AO", &h->AO}, {"F1", &h->F1},
+          {"R3", &h->R3}, {"R4", &h->R4}, {"L3", &h->L3}, {"T4", &h->T4}, {"L4", &h->L4}, {"clsb", &h->clsb}, {"pos_alt", &h->pos_alt},
+          {"lrn0", &h->lrn[0]}, {"lrn1", &h->lrn[1]}, {"lrn2", &h->lrn[2]}, {"lrn3", &h->lrn[3]}, {"tA", &h->tA}, {"tB", &h->tB},
+          {"tC", &h->tC}, {"P0", &h->P[0]}, {"P1", &h->P[1]}, {"P2", &h->P[2]}, {"P3", &h->P[3]}, {"H0", &h->H0}, {"H0U", &h->H0U},
+          {"H1", &h->H1}};
+}
+
+int dptx_debug_arena_layout(dptx_handle h, char* dst, size_t capacity) {
+  if (!h) return DPTX_E_INVALID;
+  std::string s;
+  char line[256];
+  snprintf(line, sizeof line, "arena_bytes %zu\narena_single %zu\nhalf_region %zu\nhalf_batch %d\nmax_batch %d\nn_streams %d\nplanes %d\n",
+           h->arena_bytes, h->arena_single, h->half_region, h->half_batch, h->cfg.max_batch, h->n_streams, h->two_planes() ? 2 : 1);
+  s += line;
+  for (const auto& nb : arena_buf_list(h)) {
+    snprintf(line, sizeof line, "buf %s %zu %zu %zu\n", nb.first, nb.second->off, nb.second->bytes, nb.second->off2);
+    s += line;
+  }
+  if (dst && capacity > 0) {
+    const size_t n = s.size() < capacity - 1 ? s.size() : capacity - 1;
+    memcpy(dst, s.data(), n);
+    dst[n] = 0;
+  }
+  return (int)s.size() + 1;
+}
+
+// One 64-bit word sum (order-independent) per arena buffer, sub-batch region and plane of the layout the LAST forward used, on
+// `stream` (i.e. behind that forward): out_dev[(plane * regions + region) * nbuf + buf], buffers in dptx_debug_arena_layout
+// order.  Returns the number of sums (or the capacity needed when out_dev is null).  Comparing the vectors of two forwards of
+// the same input names the first tensor that differs (tools/gpu/r4_hunt.py).
+int dptx_debug_arena_checksums(dptx_handle h, void* out_dev, int32_t capacity, void* stream) {
+  if (!h) return DPTX_E_INVALID;
+  const auto bufs = arena_buf_list(h);
+  const int nbuf = (int)bufs.size();
+  const int regions = h->last_regions > 1 ? h->last_regions : 1;
+  const int planes = h->two_planes() ? 2 : 1;
+  const int total = planes * regions * nbuf;
+  if (!out_dev) return total;
+  if (capacity < total) return h->fail(DPTX_E_INVALID, "checksum buffer too small");
+  if (h->cfg.device_id < 0 || !h->d_arena) return h->fail(DPTX_E_INVALID, "no arena");
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, hipMemsetAsync(out_dev, 0, (size_t)total * 8, st));
+  // extent of a buffer in the plan in use: up to the next buffer's offset
+  std::vector<std::pair<size_t, int>> order;
+  for (int i = 0; i < nbuf; ++i) order.push_back({regions > 1 ? bufs[i].second->off2 : bufs[i].second->off, i});
+  std::sort(order.begin(), order.end());
+  const size_t plan_end = regions > 1 ? h->half_region : h->arena_single;
+  for (int pl = 0; pl < planes; ++pl)
+    for (int r = 0; r < regions; ++r)
+      for (int k = 0; k < nbuf; ++k) {
+        const size_t off = order[k].first, end = k + 1 < nbuf ? order[k + 1].first : plan_end;
+        if (end <= off) continue;
+        const char* base = h->d_arena + (size_t)pl * h->arena_single + (regions > 1 ? (size_t)r * h->half_region : 0) + off;
+        HIPCHK(h, launch_checksum(base, end - off, (unsigned long long*)out_dev + ((size_t)pl * regions + r) * nbuf + order[k].second, st));
+      }
+  return total;
 }
 
 int dptx_debug_set_trace(void* dev_buf) {

@@ -130,6 +130,12 @@ hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int
 // fp8 calibration: atomicMax(*amax_bits, bits of max |x| (relu: max(x, 0)) over n 16-bit elements); *amax_bits starts at 0
 hipError_t launch_amax(int mode, const void* X, size_t n, int relu, unsigned* amax_bits, hipStream_t stream);
 
+// range check: *flag |= 1 if the 16-bit tensor X (n elements, n % 8 == 0; hi plane only) holds an Inf or a NaN
+hipError_t launch_nonfinite_scan(int mode, const void* X, size_t n, unsigned* flag, hipStream_t stream);
+
+// debug: *out += 64-bit sum of the 32-bit words of [p, p + bytes)
+hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t stream);
+
 // y NCHW fp32 [B,Cout,HW] = act( W[Cout][32] * x[B*HW,32] + b ),  Cout <= 4
 hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, void* y, int io, int B, int HW,
                            int Cout, int relu, Planes pl, hipStream_t stream);

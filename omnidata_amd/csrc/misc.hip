@@ -99,6 +99,49 @@ hipError_t launch_amax(int mode, const void* X, size_t n, int relu, unsigned* am
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------ range check
+// Sets *flag |= 1 when a 16-bit tensor holds an Inf or a NaN (fp16 planes overflow at 65504 and nothing in the forward
+// clamps).  The engine scans ONE tensor per forward -- the first head conv's output H0, where every decoder path has been
+// merged through residual adds (a non-finite value upstream in the ViT blocks or the decoder reaches it; ReLUs on the way
+// map NaN to 0, the residual adds next to them do not).  Integer test on the packed pairs: the exponent field is all ones
+// iff magnitude + (1 << mantissa bits) carries into the sign position.
+template <int DT>
+__global__ __launch_bounds__(256) void nonfinite_scan_kernel(const uint4* __restrict__ X, size_t n8, unsigned* __restrict__ flag) {
+  constexpr uint32_t ADD = DT == DT_FP16 ? 0x04000400u : 0x00800080u;
+  uint32_t bad = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const uint4 v = X[i];
+    bad |= ((v.x & 0x7fff7fffu) + ADD) | ((v.y & 0x7fff7fffu) + ADD) | ((v.z & 0x7fff7fffu) + ADD) | ((v.w & 0x7fff7fffu) + ADD);
+  }
+  if (bad & 0x80008000u) atomicOr(flag, 1u);
+}
+hipError_t launch_nonfinite_scan(int mode, const void* X, size_t n, unsigned* flag, hipStream_t stream) {
+  if (n % 8 != 0 || flag == nullptr) return hipErrorInvalidValue;
+  const size_t n8 = n / 8;
+  const int grid = (int)std::min<size_t>((n8 + 255) / 256, 2048);
+  if (mode == MODE_FP16 || mode == MODE_FP16X3)
+    hipLaunchKernelGGL(nonfinite_scan_kernel<DT_FP16>, dim3(grid), dim3(256), 0, stream, (const uint4*)X, n8, flag);
+  else
+    hipLaunchKernelGGL(nonfinite_scan_kernel<DT_BF16>, dim3(grid), dim3(256), 0, stream, (const uint4*)X, n8, flag);
+  return hipGetLastError();
+}
+
+// debug (dptx_debug_arena_checksums): *out += sum of the 32-bit words of [p, p + bytes) as a 64-bit integer
+__global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restrict__ p, size_t n32, unsigned long long* __restrict__ out) {
+  unsigned long long s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n32; i += (size_t)gridDim.x * 256) s += p[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(out, s);
+}
+hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t stream) {
+  const size_t n32 = bytes / 4;
+  if (n32 == 0) return hipSuccess;
+  const int grid = (int)std::min<size_t>((n32 + 255) / 256, 1024);
+  hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, stream, (const uint32_t*)p, n32, out);
+  return hipGetLastError();
+}
+
 // ----------------------------------------------------------------- head: conv1x1 32->C (+ReLU)
 // dpt_depth.py:96-98.  X [B*HW][32] 16-bit (already ReLU'd) -> y NCHW fp32 [B][C][HW].
 template <int DT, int PL>

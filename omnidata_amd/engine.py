@@ -58,6 +58,7 @@ ABI = [
     ("dptx_calibrate_fp8", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_fp8_get_calibration", C.c_int, [_vp, _f32p, _f32p, _i32]),
     ("dptx_fp8_set_calibration", C.c_int, [_vp, _f32p, _i32]),
+    ("dptx_range_status", C.c_int, [_vp, C.POINTER(C.c_int32), _i32, _vp]),
     ("dptx_tap", C.c_int, [_vp, C.c_char_p, _vp, _sz, _i64p]),
     ("dptx_enable_taps", C.c_int, [_vp, C.c_int]),
     ("dptx_forward_info", C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -80,6 +81,10 @@ ABI = [
     ("dptx_op_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     ("dptx_debug_set_trace", C.c_int, [_vp]),
     ("dptx_debug_set_gemm_flags", C.c_int, [C.c_int32]),
+    ("dptx_debug_arena_fill", C.c_int, [_vp, _i32]),
+    ("dptx_debug_arena_read", C.c_int, [_vp, _vp, _sz, _sz]),
+    ("dptx_debug_arena_layout", C.c_int, [_vp, C.c_char_p, _sz]),
+    ("dptx_debug_arena_checksums", C.c_int, [_vp, _vp, _i32, _vp]),
     ("dptx_op_conv_fp8", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [C.c_float, _vp]),
     ("dptx_op_conv_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 12 + [C.c_float, _vp, _vp]),
     ("dptx_op_upsample2x", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -89,24 +94,40 @@ ABI = [
 _lib = None
 
 
+def _embedded_hash(path: str) -> str:
+    """`src=<hash>` of a built library, read by loading it (dptx_version()); "" if it cannot be loaded."""
+    try:
+        lib = C.CDLL(path)
+        lib.dptx_version.restype = C.c_char_p
+        v = lib.dptx_version().decode()
+        return v.rsplit("src=", 1)[-1] if "src=" in v else ""
+    except (OSError, AttributeError):
+        return ""
+
+
 def load_library() -> C.CDLL:
     """Loads libdptx.so and declares every prototype.  The binary must have been built from the sources it sits next to
-    (the .so travels with the tree; mtimes prove nothing on another machine): build.py records the sha256 of csrc/* +
-    include/dptx.h next to the objects and embeds it in the library (dptx_version() ends in "src=<hash>").  A missing or
-    stale library is rebuilt here when hipcc is available (it cross-compiles without a GPU); otherwise -- or if the loaded
-    binary still reports another hash -- this raises.  There is no CPU fallback."""
+    (the .so travels with the tree; mtimes and side files prove nothing on another machine): build.py embeds the sha256 of
+    csrc/* + include/dptx.h in the library (dptx_version() ends in "src=<hash>") and THAT is what is compared with the tree
+    here -- a correct prebuilt library needs neither hipcc nor the build directory.  A missing or stale library is rebuilt
+    when hipcc is available (it cross-compiles without a GPU), by one process at a time (build.py takes a file lock and
+    links to a temporary file that is renamed into place, so ranks started together do not write one object directory at
+    once); otherwise this raises.  There is no CPU fallback."""
     global _lib
     if _lib is None:
         check = not os.environ.get("DPTX_LIB") and not os.environ.get("DPTX_SKIP_HASH_CHECK")
+        want = ""
         if check:
-            from .build import build, built_hash, source_hash
+            from .build import build, source_hash
             want = source_hash(os.environ.get("DPTX_CXXFLAGS", "").split())
-            if not os.path.exists(LIB_PATH) or built_hash() != want:
+            have = _embedded_hash(LIB_PATH) if os.path.exists(LIB_PATH) else ""
+            if have != want:
                 hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
                 if not os.path.exists(hipcc):
-                    raise RuntimeError(f"{LIB_PATH} is missing or stale (sources {want}) and {hipcc} is not available: run "
-                                       "`python -m omnidata_amd.build` on a machine with ROCm. There is no CPU fallback.")
-                build()
+                    raise RuntimeError(f"{LIB_PATH} is {'stale (built from sources ' + have + ')' if have else 'missing'}; the tree "
+                                       f"has {want} and {hipcc} is not available: run `python -m omnidata_amd.build` on a "
+                                       "machine with ROCm. There is no CPU fallback.")
+                build()  # (a stale copy mapped by _embedded_hash stays mapped under its old inode; the new file is a new one)
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not found: run `python -m omnidata_amd.build` "
                                "(or __graft_entry__.build()). There is no CPU fallback.")
@@ -163,6 +184,7 @@ class Engine:
         cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold, 2: group-level precision policy only, 4: fp32 token stream in the single-pass dtypes)
         self.cfg = cfg
         self.fp8_calibrated = False
+        self.fp8_scales = None  # the scales installed last (calibrate_fp8 / set_fp8_calibration): what a rebuilt engine re-installs
         self.dtype = dtype
         self.backbone = backbone
         self.h = _vp()
@@ -310,6 +332,7 @@ class Engine:
         self._check(self.lib.dptx_calibrate_fp8(self.h, x.data_ptr(), IO_DTYPES[x.dtype], y.data_ptr(), _ptr(y2), B, H, W,
                                                 _stream(x.device)), "calibrate_fp8")
         self.fp8_calibrated = True
+        self.fp8_scales = self.fp8_calibration()[0]
         return (y, y2) if dual else y
 
     def fp8_calibration(self):
@@ -325,6 +348,50 @@ class Engine:
         s = np.ascontiguousarray(scales, dtype=np.float32)
         self._check(self.lib.dptx_fp8_set_calibration(self.h, s.ctypes.data_as(_f32p), int(s.size)), "fp8_set_calibration")
         self.fp8_calibrated = True
+        self.fp8_scales = s.copy()
+
+    # ---- arena debugging (include/dptx.h dptx_debug_arena_*)
+    def arena_fill(self, byte_value: int):
+        """Sets every byte of the activation arena to byte_value (0xFF = NaN in every element type) after a device sync."""
+        self._check(self.lib.dptx_debug_arena_fill(self.h, int(byte_value)), "debug_arena_fill")
+
+    def arena_layout(self) -> Dict[str, object]:
+        n = self.lib.dptx_debug_arena_layout(self.h, None, 0)
+        buf = C.create_string_buffer(n)
+        self.lib.dptx_debug_arena_layout(self.h, buf, n)
+        out: Dict[str, object] = {"bufs": {}}
+        for line in buf.value.decode().splitlines():
+            f = line.split()
+            if f[0] == "buf":
+                out["bufs"][f[1]] = (int(f[2]), int(f[3]), int(f[4]))
+            else:
+                out[f[0]] = int(f[1])
+        return out
+
+    def arena_checksums(self) -> torch.Tensor:
+        """int64 device tensor [planes, regions, nbuf] of word sums of every arena buffer as the last forward left it (queued
+        on the current stream behind that forward; no host sync)."""
+        dev = torch.device("cuda", self.cfg.device_id)
+        n = self.lib.dptx_debug_arena_checksums(self.h, None, 0, None)
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+        rc = self.lib.dptx_debug_arena_checksums(self.h, out.data_ptr(), n, _stream(dev))
+        if rc < 0:
+            self._check(rc, "debug_arena_checksums")
+        nbuf = len(self.arena_layout()["bufs"])
+        planes = 2 if self.dtype in ("bf16x3", "fp16x3", "mixed", "fp8") else 1
+        return out.view(planes, n // (planes * nbuf), nbuf)
+
+    def arena_read(self, offset: int, nbytes: int) -> np.ndarray:
+        a = np.empty(nbytes, dtype=np.uint8)
+        self._check(self.lib.dptx_debug_arena_read(self.h, a.ctypes.data, offset, nbytes), "debug_arena_read")
+        return a
+
+    def range_overflowed(self, reset: bool = True) -> bool:
+        """fp16-plane dtypes: has any forward since the last reset left the fp16 range (include/dptx.h dptx_range_status)?
+        Waits for the current stream."""
+        v = C.c_int32(0)
+        self._check(self.lib.dptx_range_status(self.h, C.byref(v), int(reset), _stream(torch.device("cuda", self.cfg.device_id))), "range_status")
+        return bool(v.value)
 
     def enable_taps(self, on: bool = True):
         self._check(self.lib.dptx_enable_taps(self.h, int(on)), "enable_taps")

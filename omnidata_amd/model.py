@@ -36,7 +36,93 @@ class BaseModel(nn.Module):
         self.load_state_dict(read_checkpoint(path))
 
 
-class DPTDepthModel(BaseModel):
+class _EngineGuards:
+    """What DPTDepthModel and DPTDualTaskModel share around an engine call: the fp16 range guard and the fp8 calibration.
+
+    Range guard (``overflow_fallback``, default on).  The fp16-plane modes ('mixed', 'fp16x3', 'fp16') cannot represent
+    |x| > 65504 (two planes: ~1.3e5) and nothing inside the forward clamps; the parity claims are validated on synthetic
+    weight families only.  Every forward of such an engine scans the first head convolution's output on the device --
+    the tensor every decoder path and, through them, the ViT blocks reach by residual additions -- and ORs "non-finite"
+    into a sticky device flag (include/dptx.h dptx_range_status; ~0.3 % of a forward).  The model reads the flag after
+    the FIRST forward of a set of weights and after every ``range_check_every``-th one (one stream synchronisation
+    each): when it is set although the input was finite, the model switches to the bf16-plane mode of the same kind
+    ('bf16x3' for the parity modes, 'bf16' for 'fp16': fp32's exponent range) with a warning and recomputes the
+    current batch; between two reads at most ``range_check_every`` - 1 earlier results can be affected, which the
+    warning says.  The activations are checked, not the result: the decoder's ReLUs turn a NaN back into 0, so an
+    overflow upstream can leave a finite, wrong output.
+
+    fp8 calibration.  The per-tensor activation scales of the e4m3 copies are data: ``calibrate(x)`` measures them on a
+    representative batch.  A model that was never calibrated does it on the first batch it sees and says so (warning):
+    replicated ranks must not each calibrate on their own shard (``dist.broadcast_fp8_calibration``).  The scales
+    belong to the weights, not to the engine object: they are re-installed when the engine is rebuilt (``.to()``, a
+    larger input size) and dropped when new weights are loaded."""
+
+    _FP16_FALLBACK = {"mixed": "bf16x3", "fp16x3": "bf16x3", "fp16": "bf16"}
+    range_check_every = 16
+
+    def _init_guards(self, overflow_fallback: bool):
+        self.overflow_fallback = bool(overflow_fallback)
+        self._range_checked = None   # (values version, dtype) whose first forward came back clean
+        self._since_range_check = 0
+        self._values_version = 0     # bumped by load_state_dict only (``.to()`` moves the same values)
+        self._fp8_scales = None      # (values version, scales) of the last calibration
+
+    def _restore_fp8(self, eng):
+        """A rebuilt engine gets the scales of the same weights back."""
+        if self.engine_dtype == "fp8" and not eng.fp8_calibrated and self._fp8_scales is not None \
+                and self._fp8_scales[0] == self._values_version:
+            eng.set_fp8_calibration(self._fp8_scales[1])
+
+    def _ensure_fp8(self, eng, x):
+        if self.engine_dtype != "fp8":
+            return
+        self._restore_fp8(eng)
+        if not eng.fp8_calibrated:
+            import warnings
+            warnings.warn("omnidata_amd: dtype='fp8' model was not calibrated -- measuring the activation scales of the e4m3 "
+                          "tensors on this first batch.  Call model.calibrate(x) with a representative batch (and "
+                          "omnidata_amd.dist.broadcast_fp8_calibration across ranks) to choose them explicitly.")
+            eng.calibrate_fp8(x)
+        if eng.fp8_scales is not None:
+            self._fp8_scales = (self._values_version, eng.fp8_scales)
+
+    @torch.no_grad()
+    def calibrate(self, x: torch.Tensor):
+        """dtype='fp8' only: (re-)measures the activation ranges of the e4m3 tensors on `x` (at most max_batch images)."""
+        if self.engine_dtype != "fp8":
+            raise RuntimeError("calibrate() applies to dtype='fp8'")
+        eng = self._get_engine(x.device)
+        eng.calibrate_fp8(x[: self._chunk()])
+        self._fp8_scales = (self._values_version, eng.fp8_scales)
+
+    def _range_fallback_needed(self, eng, x: torch.Tensor) -> bool:
+        """Called after a forward.  True: the engine left the fp16 range, the model has switched to bf16 planes and the
+        caller recomputes the batch."""
+        if not (self.overflow_fallback and self.engine_dtype in self._FP16_FALLBACK):
+            return False
+        tag = (self._values_version, self.engine_dtype)
+        first = self._range_checked != tag
+        self._since_range_check += 1
+        if not first and self._since_range_check < self.range_check_every:
+            return False
+        n_since, self._since_range_check = self._since_range_check, 0
+        if not eng.range_overflowed(reset=True):
+            self._range_checked = tag
+            return False
+        if first and not bool(torch.isfinite(x).all()):
+            return False  # the input's problem, not the arithmetic's
+        import warnings
+        safe = self._FP16_FALLBACK[self.engine_dtype]
+        warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} produced non-finite activations -- a tensor exceeds the fp16 "
+                      f"range (65504) with these weights; switching this model to dtype={safe!r} (bf16 planes: fp32's range) and "
+                      f"recomputing this batch" + ("" if first else f"; up to {n_since - 1} earlier results since the last check "
+                      f"may be affected") + ".  Pass overflow_fallback=False to keep the dtype.")
+        self.engine_dtype = safe
+        self.x3_groups = 0
+        return True
+
+
+class DPTDepthModel(_EngineGuards, BaseModel):
     """Drop-in for ``DPTDepthModel(backbone={'vitb_rn50_384' | 'vitl16_384'}, num_channels={1,3})``
     (DPT-Hybrid, the published omnidata configuration, and DPT-Large, demo.py:81 / dpt_depth.py:41-45).
 
@@ -49,19 +135,9 @@ class DPTDepthModel(BaseModel):
     faster, but ~6e-2 / ~9e-3 max-abs from the reference on the seeded weights -- NOT within 1e-3; 'fp8' additionally
     runs the decoder convolutions on e4m3 operands.  ``max_batch`` -- arena size (larger batches are chunked).
 
-    ``overflow_fallback`` (default on): the fp16-plane modes ('mixed', 'fp16x3', 'fp16') cannot represent |x| > 65504
-    (two planes: ~1.3e5), and nothing inside the forward clamps.  The parity claims are validated on synthetic weight
-    families only (the published checkpoints cannot be fetched where this was built), so the FIRST image a set of weights
-    sees is run once more with the stage taps on and every tap (21 stage boundaries) is scanned: a
-    non-finite activation from finite input switches the model to the bf16-plane mode of the same kind ('bf16x3' for the
-    parity modes, 'bf16' for 'fp16' -- bf16 has fp32's range) with a warning.  The taps are read, not the result: the
-    ReLUs of the decoder turn a NaN back into 0 (v_max_f32 returns its non-NaN operand), so an overflow upstream can
-    leave a finite, wrong output.  One extra single-image forward and host copy on that first call, nothing afterwards.
+    ``overflow_fallback`` (default on): the fp16 range guard described in ``_EngineGuards`` -- an on-device scan per
+    forward, read after the first forward of a set of weights and every 16th one afterwards; falls back to bf16 planes.
     """
-
-    _FP16_FALLBACK = {"mixed": "bf16x3", "fp16x3": "bf16x3", "fp16": "bf16"}
-    _RANGE_TAPS = ("stem", "s0", "s1", "s2", "tok0", "blk0", "blk3", "blk5", "blk8", "blk11", "blk17", "blk23", "l1", "l2", "l3",
-                   "l4", "l1_rn", "l2_rn", "l3_rn", "l4_rn", "p4", "p3", "p2", "p1", "h0", "h1")
 
     def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,
                  backbone: str = "vitb_rn50_384", features: int = 256, readout: str = "project",
@@ -83,8 +159,7 @@ class DPTDepthModel(BaseModel):
         self.channels_last = channels_last  # accepted and, as in the reference (dpt_depth.py:68-69), a no-op
         self.engine_dtype = dtype
         self.x3_groups = x3_groups
-        self.overflow_fallback = bool(overflow_fallback)
-        self._range_checked = None  # (weights version, dtype) whose first batch came back finite
+        self._init_guards(overflow_fallback)
         self.max_batch = max(1, min(int(max_batch), 48))  # engine limit; larger batches are chunked in forward()
         self.max_hw = (384, 384)  # arena is planned for this input size; grows on demand (forward_flex, vit.py:119)
         init = random_state_dict(init_seed, num_channels, backbone=backbone)
@@ -106,6 +181,7 @@ class DPTDepthModel(BaseModel):
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
         self._weights_version += 1
+        self._values_version += 1
         return r
 
     def _apply(self, fn, *a, **kw):
@@ -140,13 +216,6 @@ class DPTDepthModel(BaseModel):
         self._engine_key = (device_index, self._weights_version, self.engine_dtype, self._chunk(), self.max_hw)
 
     @torch.no_grad()
-    def calibrate(self, x: torch.Tensor):
-        """dtype='fp8' only: (re-)measures the activation ranges of the e4m3 tensors on `x` (at most max_batch images)."""
-        if self.engine_dtype != "fp8":
-            raise RuntimeError("calibrate() applies to dtype='fp8'")
-        self._get_engine(x.device).calibrate_fp8(x[: self._chunk()])
-
-    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("omnidata_amd.DPTDepthModel runs only on an AMD GPU (HIP); got a CPU tensor. "
@@ -158,52 +227,19 @@ class DPTDepthModel(BaseModel):
             self.max_hw = (H, W)  # re-plans the arena (and re-packs the weights) once for the larger size
         eng = self._get_engine(x.device)
         step = self._chunk()
-        if self.engine_dtype == "fp8" and not eng.fp8_calibrated:
-            # per-tensor activation scales of the e4m3 copies: measured once, on the first batch this model sees
-            # (include/dptx.h dptx_calibrate_fp8; call model.calibrate(x) with a representative batch to choose it)
-            eng.calibrate_fp8(x[:step])
-        tag = (self._weights_version, self.engine_dtype)
-        if self.overflow_fallback and self.engine_dtype in self._FP16_FALLBACK and self._range_checked != tag:
-            if self._fp16_range_ok(eng, x[:1]):
-                self._range_checked = tag
-            else:
-                import warnings
-                safe = self._FP16_FALLBACK[self.engine_dtype]
-                warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} produced non-finite activations from finite input -- a "
-                              f"tensor exceeds the fp16 range (65504) with these weights; switching this model to "
-                              f"dtype={safe!r} (bf16 planes: fp32's range).  Pass overflow_fallback=False to keep the dtype.")
-                self.engine_dtype = safe
-                self.x3_groups = 0
-                return self.forward(x)
+        self._ensure_fp8(eng, x[:step])
         if B <= step:
             y = eng.forward(x)
         else:
             y = torch.empty(B, self.num_channels, H, W, dtype=_io_dtype(x), device=x.device)
             for i in range(0, B, step):
                 eng.forward(x[i:i + step], out=y[i:i + step])
+        if self._range_fallback_needed(eng, x):
+            return self.forward(x)  # on the bf16-plane engine
         return y.squeeze(dim=1)  # dpt_depth.py:106-107
 
-    def _fp16_range_ok(self, eng: Engine, x1: torch.Tensor) -> bool:
-        """One forward of x1 with the stage taps on; False if any tap holds a non-finite value although x1 is finite."""
-        if not bool(torch.isfinite(x1).all()):
-            return True  # the input's problem, not the arithmetic's
-        was_on = getattr(eng, "taps_on", False)  # a caller who records taps keeps doing so
-        eng.enable_taps(True)
-        try:
-            eng.forward(x1)
-            for name in self._RANGE_TAPS:
-                try:
-                    t = eng.tap(name)
-                except RuntimeError:
-                    continue  # a tap of the other backbone
-                if not bool(torch.isfinite(t).all()):
-                    return False
-            return True
-        finally:
-            eng.enable_taps(was_on)
 
-
-class DPTDualTaskModel(nn.Module):
+class DPTDualTaskModel(_EngineGuards, nn.Module):
     """Surface normals AND depth from one encoder pass (BASELINE.json configs[4]).
 
     ``pretrained.*`` (ResNetV2-50 + ViT-B + read-outs) runs once; ``scratch.*`` (normal decoder, 3 channels) and
@@ -216,8 +252,9 @@ class DPTDualTaskModel(nn.Module):
     """
 
     def __init__(self, dtype: str = "mixed", max_batch: int = 32, init_seed: int = 0, non_negative: bool = True,
-                 x3_groups=0):
+                 x3_groups=0, overflow_fallback: bool = True):
         super().__init__()
+        self._init_guards(overflow_fallback)
         self.engine_dtype = dtype
         self.x3_groups = x3_groups
         self.max_batch = max(1, min(int(max_batch), 48))
@@ -246,6 +283,7 @@ class DPTDualTaskModel(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
         self._weights_version += 1
+        self._values_version += 1
         return r
 
     def _apply(self, fn, *a, **kw):
@@ -283,12 +321,13 @@ class DPTDualTaskModel(nn.Module):
             self.max_hw = (H, W)
         eng = self._get_engine(x.device)
         step = self._chunk()
-        if self.engine_dtype == "fp8" and not eng.fp8_calibrated:
-            eng.calibrate_fp8(x[:step])  # activation scales of the e4m3 tensors, measured on the first batch
+        self._ensure_fp8(eng, x[:step])
         yn = torch.empty(B, 3, H, W, dtype=_io_dtype(x), device=x.device)
         yd = torch.empty(B, 1, H, W, dtype=_io_dtype(x), device=x.device)
         for i in range(0, B, step):
             eng.forward_dual(x[i:i + step], out_normal=yn[i:i + step], out_depth=yd[i:i + step])
+        if self._range_fallback_needed(eng, x):
+            return self.forward(x)  # on the bf16-plane engine
         return yn, yd.squeeze(dim=1)
 
 

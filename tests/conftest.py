@@ -17,9 +17,9 @@ def pytest_configure(config):
 # fused-vs-unfused, stream schedules, dual-vs-single, CLI plumbing) last -- with `-x`, a failing self-comparison can no
 # longer hide the parity evidence.
 _FILE_RANK = ["test_gpu_ops.py", "test_gpu_x3.py", "test_gpu_mixed.py", "test_gpu_e2e.py", "test_gpu_vitl16.py", "test_gpu_flex.py",
-              "test_gpu_prepost.py", "test_gpu_fp8.py", "test_gpu_dual.py", "test_gpu_cli.py", "test_gpu_stress.py"]
+              "test_gpu_prepost.py", "test_gpu_fp8.py", "test_gpu_dual.py", "test_gpu_cli.py", "test_gpu_poison.py", "test_gpu_stress.py"]
 _SELF_COMPARISONS = ("deterministic", "fused_head_equals", "two_stream", "packed_blob", "bitwise", "bit_identical", "stress",
-                     "input_contract")
+                     "input_contract", "prior_arena")
 
 
 def pytest_collection_modifyitems(session, config, items):

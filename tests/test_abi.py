@@ -63,8 +63,9 @@ def test_strict_loading_errors(built_lib):
 
 
 def _blob_offsets(spec_items, dtype_bytes=2):
-    """Re-derives the packed layout: entries in spec order, 256-B aligned."""
-    off, out = 0, {}
+    """Re-derives the packed layout: a 256-byte layout header (engine.hip BlobHeader), then the entries in spec order,
+    256-B aligned."""
+    off, out = 256, {}
     for k, shape in spec_items:
         if is_unused(k):
             continue
@@ -188,7 +189,7 @@ def test_bf16x3_packing_has_hi_and_lo_planes(built_lib):
     e3.load_state_dict(sd)
     b1, b3 = e1.export_packed_host(), e3.export_packed_host()
     assert b3.size == 2 * b1.size == e3.packed_bytes
-    assert np.array_equal(b3[: b1.size], b1)
+    assert np.array_equal(b3[256: b1.size], b1[256:])   # behind the layout header (dtype, sizes)
     offs, _ = _blob_offsets(state_dict_spec(3).items())
     k = "pretrained.model.blocks.2.mlp.fc2.weight"
     o, b = offs[k]

@@ -57,6 +57,58 @@ def test_dual_vs_oracle(hw):
             assert (ssi_align(yd, rd) - rd).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("B", [1, 32])
+def test_default_dual_model_is_the_parity_mode(B):
+    """DPTDualTaskModel defaults to dtype 'mixed' and nothing compared that forward with the oracle.  Both heads
+    of the DEFAULT dual model against the reference forward run twice on tied weights (oracle.dpt_forward_dual), at B = 1
+    and at B = 32 (two streams, 256x256 tiles) on all 32 images: within north_star's 1e-3."""
+    oracle_threads()
+    sd = random_dual_state_dict(6)
+    x = synthetic_input(13, B, "normal")
+    dual = DPTDualTaskModel(max_batch=B)
+    assert dual.engine_dtype == "mixed"
+    dual.load_state_dict(sd)
+    dual.to(DEV)
+    yn, yd = [t.cpu() for t in dual(x.to(DEV))]
+    assert dual.engine_dtype == "mixed"        # the range guard saw nothing
+    dn = dd = 0.0
+    for i in range(0, B, 8):                   # the oracle in chunks of 8 images (memory)
+        rn, rd = dpt_forward_dual(sd, x[i:i + 8])
+        dn = max(dn, (yn[i:i + 8] - rn).abs().max().item())
+        dd = max(dd, (yd[i:i + 8] - rd).abs().max().item())
+    print(f"\n[dual mixed B={B}] max|d| normal={dn:.3e} depth={dd:.3e}")
+    assert dn < 1e-3 and dd < 1e-3
+
+
+def test_dual_model_leaves_fp16_planes_when_they_overflow():
+    """the dual-task model has the fp16 range guard of DPTDepthModel.  Both decoders re-parameterised to
+    1e8 x larger internal activations (same function): the default dual model falls back to bf16x3 and matches the oracle."""
+    import warnings
+    oracle_threads()
+    sd = random_dual_state_dict(6)
+    x = synthetic_input(13, 1, "normal")
+    rn, rd = dpt_forward_dual(sd, x)
+    big = {k: v.clone() for k, v in sd.items()}
+    for k in big:
+        kk = k[6:] if k.startswith("depth.") else k
+        if kk.startswith("scratch.layer") and kk.endswith("_rn.weight"):
+            big[k] *= 1.0e8
+        if kk.startswith("scratch.refinenet") and kk.endswith(".bias"):
+            big[k] *= 1.0e8
+        if kk == "scratch.output_conv.0.weight":
+            big[k] /= 1.0e8
+    dual = DPTDualTaskModel(max_batch=1)
+    dual.load_state_dict(big)
+    dual.to(DEV)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        yn, yd = [t.cpu() for t in dual(x.to(DEV))]
+    assert dual.engine_dtype == "bf16x3" and any("fp16 range" in str(i.message) for i in w)
+    dn, dd = (yn - rn).abs().max().item(), (yd - rd).abs().max().item()
+    print(f"\n[dual 1e8x activations -> bf16x3] max|d| normal={dn:.3e} depth={dd:.3e}")
+    assert dn < 1e-3 and dd < 1e-3
+
+
 def test_dual_taps_and_contract():
     sd = random_dual_state_dict(3)
     dual = DPTDualTaskModel(dtype="bf16", max_batch=2)

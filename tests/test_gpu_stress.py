@@ -13,25 +13,67 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _stress(dtype, dual, B, streams, iters):
+    from omnidata_amd.weights import random_dual_state_dict
+    sd = random_dual_state_dict(0) if dual else random_state_dict(0, 3)
+    x = synthetic_input(5, B, "normal").to(DEV)
+
+    def make(ns):
+        e = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, dual=dual, streams=ns)
+        e.load_state_dict(sd)
+        return e
+
+    def fwd(e, out, out2):
+        if dual:
+            e.forward_dual(x, out_normal=out, out_depth=out2)
+        else:
+            e.forward(x, out=out)
+    ref_eng = make(1)
+    if dtype == "fp8":
+        ref_eng.calibrate_fp8(x)
+        scales, _ = ref_eng.fp8_calibration()
+    ref, ref2 = torch.empty(B, 3, 384, 384, device=DEV), torch.empty(B, 1, 384, 384, device=DEV)
+    fwd(ref_eng, ref, ref2)
+    torch.cuda.synchronize()
+    ref_eng.close()
+    eng = make(streams)
+    if dtype == "fp8":
+        eng.set_fp8_calibration(scales)
+    out, out2 = torch.empty_like(ref), torch.empty_like(ref2)
+    # every forward is checked on the device without stalling the streams (the comparison kernels queue up behind the join
+    # event on the caller's stream).  The outputs are NaN-filled on the caller's stream first: a comparison that ran before
+    # the sub-streams had written them would see NaN, not the identical result of the previous forward (round 3's form of
+    # this test re-used the buffers as they were and could not have seen an unordered join)
+    mism = torch.zeros((), dtype=torch.int64, device=DEV)
+    bad_forwards = torch.zeros((), dtype=torch.int64, device=DEV)
+    for _ in range(iters):
+        out.fill_(float("nan"))
+        if dual:
+            out2.fill_(float("nan"))
+        fwd(eng, out, out2)
+        d = (out != ref).sum() + ((out2 != ref2).sum() if dual else 0)
+        mism += d
+        bad_forwards += (d > 0).long()
+    assert int(bad_forwards.item()) == 0, f"{int(bad_forwards.item())} of {iters} forwards differ ({int(mism.item())} elements)"
+    eng.close()
+
+
 @pytest.mark.parametrize("dtype,streams,iters", [("bf16", 2, 1000), ("bf16", 3, 300), ("mixed", 2, 400)])
 def test_multi_stream_schedule_stress_bit_identical(dtype, streams, iters):
     """bf16: the benched throughput mode; mixed: the parity mode (two-plane arena, 3-MFMA tiles, the default dtype of the
-    drop-in surface)."""
-    sd = random_state_dict(0, 3)
-    B = 6
-    x = synthetic_input(5, B, "normal").to(DEV)
-    ref_eng = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, streams=1)
-    ref_eng.load_state_dict(sd)
-    ref = ref_eng.forward(x).clone()
-    ref_eng.close()
-    eng = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, streams=streams)
-    eng.load_state_dict(sd)
-    out = torch.empty_like(ref)
-    # every forward is checked on the device without stalling the streams (the comparison kernels queue up behind the
-    # join event on the caller's stream while the next forward's sub-batches already run on the internal streams)
-    mism = torch.zeros((), dtype=torch.int64, device=DEV)
-    for _ in range(iters):
-        eng.forward(x, out=out)
-        mism += (out != ref).sum()
-    assert int(mism.item()) == 0
-    eng.close()
+    drop-in surface).  B = 6: two or three images per stream -- small launches, i.e. the most concurrency between the
+    streams."""
+    _stress(dtype, False, 6, streams, iters)
+
+
+@pytest.mark.parametrize("dual,B,iters", [(False, 32, 150), (True, 32, 100), (True, 3, 600), (False, 3, 600)])
+def test_fp8_stress_bit_identical(dual, B, iters):
+    """VERDICT r3 (item 1c): the fp8 decoder under the two-stream schedule, single- and dual-task, at the benchmarked batch
+    and at the batch of the round-3 driver failure (B = 3: sub-batches of 2 + 1), against the single-stream result."""
+    _stress("fp8", dual, B, 2, iters)
+
+
+@pytest.mark.parametrize("dtype,B,iters", [("bf16", 32, 200), ("mixed", 32, 100), ("bf16", 2, 1500)])
+def test_batch_sizes_stress_bit_identical(dtype, B, iters):
+    """The benchmarked batch (256x256 persistent tiles, register-direct epilogue) and the smallest split batch."""
+    _stress(dtype, False, B, 2, iters)

@@ -150,8 +150,10 @@ def test_dual_task_spec_and_packing():
     assert dual.packed_bytes > one.packed_bytes
     blob = dual.export_packed_host()
     one.load_state_dict(nsd)
-    # the normal model's blob is a prefix of the dual blob (same key order, decoder 2 appended)
-    assert (blob[:one.packed_bytes] == one.export_packed_host()).all()
+    # behind the 256-byte layout header (which names dual_task and the sizes), the normal model's blob is a prefix of the
+    # dual blob (same key order, decoder 2 appended)
+    assert (blob[256:one.packed_bytes] == one.export_packed_host()[256:]).all()
+    assert bytes(blob[:8]) == b"DPTXBLOB" and (blob[:256] != one.export_packed_host()[:256]).any()
     with pytest.raises(RuntimeError):
         Engine(num_channels=1, max_batch=1, device_id=None, dual=True)  # dual needs the 3-channel primary
 
@@ -224,36 +226,50 @@ class _FakeCudaTensor(torch.Tensor):
 
 
 class _StubEngine:
-    """Stands in for omnidata_amd.engine.Engine: records calls; its stage taps are non-finite in the fp16-plane dtypes."""
+    """Stands in for omnidata_amd.engine.Engine: records calls; its range flag is set by every forward in the fp16-plane
+    dtypes when `overflow` is on (sticky until read with reset, like dptx_range_status)."""
     def __init__(self, dtype, overflow):
-        self.dtype, self.overflow, self.taps_on = dtype, overflow, False
+        self.dtype, self.overflow = dtype, overflow
         self.calls = []
-
-    def enable_taps(self, on=True):
-        self.taps_on = bool(on)
-        self.calls.append(("taps", bool(on)))
+        self.flag = False
+        self.fp8_calibrated, self.fp8_scales = False, None
 
     def forward(self, x, out=None):
-        self.calls.append(("forward", int(x.shape[0]), self.taps_on))
+        self.calls.append(("forward", int(x.shape[0])))
+        if self.overflow and self.dtype in ("mixed", "fp16x3", "fp16"):
+            self.flag = True
         y = torch.zeros(x.shape[0], 3, x.shape[2], x.shape[3])
         if out is not None:
             out.copy_(y)
         return y
 
-    def tap(self, name):
-        if name in ("blk17", "blk23", "l1", "l2"):
-            raise RuntimeError("unknown or unavailable tap")   # taps of the other backbone
-        t = torch.ones(1, 4, 2, 2)
-        if self.overflow and self.dtype in ("mixed", "fp16x3", "fp16") and name == "l2_rn":
-            t[0, 0, 0, 0] = float("nan")
-        return t
+    def forward_dual(self, x, out_normal=None, out_depth=None):
+        self.calls.append(("forward_dual", int(x.shape[0])))
+        if self.overflow and self.dtype in ("mixed", "fp16x3", "fp16"):
+            self.flag = True
+        return out_normal, out_depth
+
+    def range_overflowed(self, reset=True):
+        self.calls.append(("range", bool(reset)))
+        v = self.flag
+        if reset:
+            self.flag = False
+        return v
+
+    def calibrate_fp8(self, x):
+        self.calls.append(("calibrate", int(x.shape[0])))
+        self.fp8_calibrated, self.fp8_scales = True, [1.0, 2.0]
+
+    def set_fp8_calibration(self, s):
+        self.calls.append(("set_scales", list(s)))
+        self.fp8_calibrated, self.fp8_scales = True, list(s)
 
     def close(self):
         pass
 
 
-def _stubbed_model(monkeypatch, dtype, overflow, **kw):
-    model = DPTDepthModel(num_channels=3, dtype=dtype, max_batch=4, **kw)
+def _stubbed_model(monkeypatch, dtype, overflow, cls=DPTDepthModel, **kw):
+    model = cls(dtype=dtype, max_batch=4, **({"num_channels": 3} if cls is DPTDepthModel else {}), **kw)
     engines = []
 
     def get_engine(device):
@@ -265,42 +281,94 @@ def _stubbed_model(monkeypatch, dtype, overflow, **kw):
 
 
 def test_fp16_overflow_fallback_control_flow(monkeypatch):
-    """Host logic of DPTDepthModel's fp16 range check (the GPU test test_default_model_leaves_fp16_planes_when_they_overflow
-    exercises it on real overflow): first image with taps on, fallback dtype per mode, one check per set of weights, the
-    caller's tap recording restored, no check for the bf16-plane dtypes, for non-finite input, or when switched off."""
+    """Host logic of the fp16 range guard (model._EngineGuards; the GPU test
+    test_default_model_leaves_fp16_planes_when_they_overflow exercises it on real overflow): the device flag is read after
+    the first forward of a set of weights and after every 16th one, fallback dtype per mode, the batch is recomputed on the
+    bf16-plane engine, no read for the bf16-plane dtypes or when switched off, both model classes."""
+    from omnidata_amd.model import DPTDualTaskModel
     x = torch.rand(3, 3, 64, 64).as_subclass(_FakeCudaTensor)
-    # healthy weights: one single-image forward with taps, then the real one; the second call does not check again
+    # healthy weights: the flag is read after the first forward, then not again until the 16th forward after it
     model, engines = _stubbed_model(monkeypatch, "mixed", overflow=False)
     model(x)
-    assert engines[0].calls == [("taps", True), ("forward", 1, True), ("taps", False), ("forward", 3, False)]
+    assert engines[0].calls == [("forward", 3), ("range", True)]
+    for _ in range(15):
+        model(x)
+    assert engines[0].calls.count(("range", True)) == 1
     model(x)
-    assert engines[0].calls[4:] == [("forward", 3, False)] and model.engine_dtype == "mixed"
-    # new weights: checked again
-    model._weights_version += 1
+    assert engines[0].calls.count(("range", True)) == 2 and model.engine_dtype == "mixed"
+    # new weights: read again after their first forward
+    model.load_state_dict(model.state_dict())
+    n = engines[0].calls.count(("range", True))
     model(x)
-    assert ("forward", 1, True) in engines[0].calls[5:]
-    # overflow: warning, bf16 planes of the same kind, result computed by the new engine
+    assert engines[0].calls.count(("range", True)) == n + 1
+    # overflow: warning, bf16 planes of the same kind, the batch recomputed by the new engine
     for dtype, safe in (("mixed", "bf16x3"), ("fp16x3", "bf16x3"), ("fp16", "bf16")):
         model, engines = _stubbed_model(monkeypatch, dtype, overflow=True)
         with pytest.warns(UserWarning, match="fp16 range"):
             model(x)
         assert model.engine_dtype == safe and len(engines) == 2
-        assert engines[1].calls == [("forward", 3, False)]          # no check in the bf16-plane dtype
-        assert ("forward", 3, False) not in engines[0].calls        # the overflowing engine never produced the result
-    # a caller who records taps keeps recording
+        assert engines[1].calls == [("forward", 3)]          # no flag read in the bf16-plane dtype
+    # an overflow that starts LATER (another input) is caught by the periodic read, and the warning says how far back
     model, engines = _stubbed_model(monkeypatch, "mixed", overflow=False)
-    model._get_engine(None).enable_taps(True)
     model(x)
-    assert engines[0].taps_on and engines[0].calls[-1] == ("forward", 3, True)
-    # switched off / dtype without fp16 planes / non-finite input: no check, no fallback
+    engines[0].overflow = True
+    with pytest.warns(UserWarning, match="earlier results"):
+        for _ in range(16):
+            model(x)
+    assert model.engine_dtype == "bf16x3"
+    # the dual-task model has the same guard (ADVICE r3)
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=True, cls=DPTDualTaskModel)
+    with pytest.warns(UserWarning, match="fp16 range"):
+        model(x)
+    assert model.engine_dtype == "bf16x3" and engines[1].calls == [("forward_dual", 3)]
+    # switched off / dtype without fp16 planes / non-finite input: no fallback
     model, engines = _stubbed_model(monkeypatch, "mixed", overflow=True, overflow_fallback=False)
     model(x)
-    assert model.engine_dtype == "mixed" and engines[0].calls == [("forward", 3, False)]
+    assert model.engine_dtype == "mixed" and engines[0].calls == [("forward", 3)]
     model, engines = _stubbed_model(monkeypatch, "bf16", overflow=True)
     model(x)
-    assert engines[0].calls == [("forward", 3, False)]
+    assert engines[0].calls == [("forward", 3)]
     bad = x.clone()
     bad[0, 0, 0, 0] = float("inf")
     model, engines = _stubbed_model(monkeypatch, "mixed", overflow=True)
     model(bad.as_subclass(_FakeCudaTensor))
-    assert model.engine_dtype == "mixed" and ("forward", 3, False) in engines[0].calls
+    assert model.engine_dtype == "mixed" and ("forward", 3) in engines[0].calls
+
+
+def test_fp8_calibration_is_explicit_or_announced_and_survives_engine_rebuilds(monkeypatch):
+    """implicit calibration on the first batch warns; the scales belong to the weights -- a rebuilt
+    engine (.to(), larger input) gets them back without a new calibration, new weights drop them."""
+    x = torch.rand(3, 3, 64, 64).as_subclass(_FakeCudaTensor)
+    model = DPTDepthModel(num_channels=3, dtype="fp8", max_batch=4)
+    engines = []
+
+    def get_engine(device):
+        if not engines or engines[-1].rebuilt:
+            engines.append(_StubEngine("fp8", False))
+            engines[-1].rebuilt = False
+        return engines[-1]
+    monkeypatch.setattr(model, "_get_engine", get_engine)
+    with pytest.warns(UserWarning, match="not calibrated"):
+        model(x)
+    assert engines[0].calls[0] == ("calibrate", 3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model(x)                                   # calibrated: silent, no second calibration
+        engines[0].rebuilt = True                  # e.g. .to(): a new engine object for the same weights
+        model(x)
+    assert engines[1].calls[0] == ("set_scales", [1.0, 2.0]) and ("calibrate", 3) not in engines[1].calls
+    model.load_state_dict(model.state_dict())      # new values: the old scales do not apply
+    engines[1].rebuilt = True
+    with pytest.warns(UserWarning, match="not calibrated"):
+        model(x)
+    assert engines[2].calls[0] == ("calibrate", 3)
+    # explicit calibration: no warning
+    model2 = DPTDepthModel(num_channels=3, dtype="fp8", max_batch=4)
+    e2 = _StubEngine("fp8", False)
+    monkeypatch.setattr(model2, "_get_engine", lambda device: e2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model2.calibrate(x)
+        model2(x)
+    assert e2.calls[:2] == [("calibrate", 3), ("forward", 3)]
