@@ -314,6 +314,10 @@ int dptx_debug_arena_layout(dptx_handle h, char* dst, size_t capacity);
  * dptx_debug_arena_layout.  Returns the number of sums; with out_dev = NULL the capacity needed.  Two forwards of one input
  * must give the same vector; the first entry that differs names the tensor (tools/gpu/r4_hunt.py). */
 int dptx_debug_arena_checksums(dptx_handle h, void* out_dev, int32_t capacity, void* stream);
+/* Word sums of the ViT buffers {lnst, Hn, QKV, AO, F1} after every launch of the ViT blocks of the following single-stream
+ * forwards: dev_buf[launch * 5 + buffer] (uint64 device memory, capacity entries; launch 0 = after the cls rows, then qkv /
+ * attention / proj / fc1 / fc2 per block).  NULL switches it off. */
+int dptx_debug_set_launch_sums(dptx_handle h, void* dev_buf, int32_t capacity);
 /* Debug / tests: process-wide switches of the 256x256 GEMM kernel's launch form -- 1: staged epilogue instead of the
  * register-direct one, 2: one block per tile instead of the persistent tile loop.  Results do not depend on them. */
 int dptx_debug_set_gemm_flags(int32_t flags);
@@ -334,6 +338,11 @@ int dptx_op_conv_groupnorm(int32_t dtype, const void* X, const void* Wt, void* Y
 /* bilinear x2, align_corners=True, NHWC 16-bit. */
 int dptx_op_upsample2x(int32_t dtype, const void* X, void* Y, int32_t B, int32_t H, int32_t W,
                        int32_t C, void* stream);
+/* Dense GEMM with the consumer epilogue of the LayerNorm fold (what the qkv / fc1 launches run): C[M,N] (16-bit) =
+ * act((A[M,K] W[N,K]^T - mu colsum) rstd + bias), with (mu, rstd) of row m combined from the (sum, sum of squares) records
+ * ln_stats[m][0 .. ln_nblk) (float2, row stride 8 records; ln_nblk = K / 128 = 6 or 8) and ln_colsum[n] = sum_k W[n][k]. */
+int dptx_op_gemm_ln(int32_t dtype, const void* A, const void* W, const float* bias, void* C, int32_t M, int32_t N, int32_t K,
+                    int32_t act, const float* ln_stats, const float* ln_colsum, int32_t ln_nblk, float ln_eps, void* stream);
 /* Fused tail of the head (dpt_depth.py:93-98): Interpolate(x2, bilinear, align_corners=True) -> Conv2d(128,32,3,pad 1)
  * -> ReLU -> Conv2d(32,C,1) -> ReLU(if relu_out).  H0 NHWC 16-bit [B,Hs,Ws,128]; W2 16-bit [32][3][3][128]
  * (O,kh,kw,I); b2 fp32[32]; w4 fp32 [C][32]; b4 fp32[C]; y NCHW fp32 [B,C,2Hs,2Ws].  BF16 / FP16 only; C <= 3. */

@@ -13,6 +13,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdptx.so")
 SOURCES = ["gemm.hip", "gemm_fp16.hip", "gemm_fp16e.hip", "gemm_x3.hip", "gemm_fp8.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip", "prepost.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_impl.h", os.path.join("..", "..", "include", "dptx.h")]
+# Per-source compiler flags.  norm.hip / misc.hip (HBM-bound glue) are built without packed fp32 arithmetic: hipcc's SLP
+# vectoriser otherwise emits v_pk_add_f32 / v_pk_fma_f32 with op_sel swizzles there (low lane reading a high dword), the
+# form that misbehaved in the GEMM epilogue next to a co-resident kernel (csrc/gemm_impl.h ln_fold_fma); these
+# kernels do not need the packed rate.  tests/test_build_quality.py checks every unit's ISA for that form.
+SOURCE_FLAGS = {"norm.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+                "misc.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 EXPERIMENT_HEADERS = [os.path.join("experiments", "gemm_experiments.h"), os.path.join("experiments", "gemm_experiments_dispatch.h")]
 
 
@@ -28,6 +34,7 @@ def source_hash(extra_flags=()) -> str:
         with open(path, "rb") as f:
             h.update(f.read())
     h.update(" ".join(extra_flags).encode())
+    h.update(repr(sorted(SOURCE_FLAGS.items())).encode())
     return h.hexdigest()[:16]
 
 
@@ -78,7 +85,7 @@ def _build_locked(force: bool, verbose: bool, suffix: str, objdir: str) -> str:
         objs.append(o)
         if not force and _newer(o, [s] + hdrs) and not (src == "engine.hip" and old_hash != src_hash):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + SOURCE_FLAGS.get(src, []) + extra + ["-c", s, "-o", o]
         if src == "engine.hip":
             cmd.insert(-4, f'-DDPTX_SRC_HASH="{src_hash}"')
         if verbose:

@@ -392,11 +392,15 @@ struct dptx_engine {
            !(cfg.flags & DPTX_FLAG_NO_RANGE_CHECK);
   }
   void* q8(const void* p) const { return d_arena + arena_single + ((const char*)p - d_arena) / 2; }  // e4m3 copy of an arena tensor
-  // fused head tail (head.hip): single-plane head, no stage taps wanted; DPTX_HEAD_FUSED=0 keeps the three launches
+  // fused head tail (head.hip): no stage taps wanted; a 3-MFMA second head conv has its fused form for fp16 planes only
+  // (head_tail_x3_kernel: "mixed", fp16x3); DPTX_HEAD_FUSED=0 keeps the three launches (DPTX_HEAD_FUSED_X3=0: for the x3 form only)
   bool head_fused(bool conv2_x3) const {
-    static int env = -1;
+    static int env = -1, env3 = -1;
     if (env < 0) { const char* t = getenv("DPTX_HEAD_FUSED"); env = (t && t[0] == '0') ? 0 : 1; }
-    return env == 1 && !conv2_x3 && !taps_on;
+    if (env3 < 0) { const char* t = getenv("DPTX_HEAD_FUSED_X3"); env3 = (t && t[0] == '0') ? 0 : 1; }
+    if (env != 1 || taps_on) return false;
+    if (!conv2_x3) return true;
+    return env3 == 1 && (cfg.dtype == DPTX_DTYPE_MIXED || cfg.dtype == DPTX_DTYPE_FP16X3);
   }
   size_t tok_tap_stride = 0;      // floats per token-stream snapshot
   float* d_tok_taps = nullptr;  // [13][max_batch*(max tokens)*768] fp32 copies of the token stream (taps_on)
@@ -404,6 +408,9 @@ struct dptx_engine {
   double exec_macs = 0.0;
   int last_batch = 0;
   int last_regions = 1;  // sub-batch regions the last forward used (1: the whole-batch plan)
+  // debug (dptx_debug_set_launch_sums): word sums of the ViT buffers after every launch of the ViT blocks, [launch][5] uint64
+  unsigned long long* d_lsums = nullptr;
+  int lsum_cap = 0, lsum_n = 0;
   // optional per-launch timing (one event after every launch; kernels are serialized on the stream)
   bool profiling = false;
   std::vector<hipEvent_t> events;
@@ -958,6 +965,20 @@ int Run::forward(const void* x, void* y, void* y2) {
     E->taps[name] = TapInfo{dst, {B, S, D_VIT, 1}, true, dt};
   };
   tok_tap(0, "tok0");
+  // debug: word sums of {lnst, Hn, QKV, AO, F1} after a launch (single-stream forwards only; tools/gpu/r4_hunt3.py)
+  auto vit_sums = [&]() {
+    if (!E->d_lsums || half) return;
+    const Buf* bufs[5] = {&E->lnst, &E->Hn, &E->QKV, &E->AO, &E->F1};
+    const size_t bytes[5] = {(size_t)M * 8 * 8, tok_elems * 2, (size_t)M * 3 * D_VIT * 2, tok_elems * 2, (size_t)M * D_MLP * 2};
+    if (E->lsum_n + 5 > E->lsum_cap) return;
+    for (int i = 0; i < 5; ++i) {
+      const hipError_t r = launch_checksum(A(*bufs[i]), bytes[i], E->d_lsums + E->lsum_n + i, st);
+      if (err == hipSuccess && r != hipSuccess) { err = r; where = "vit_sums"; }
+    }
+    E->lsum_n += 5;
+  };
+  if (E->d_lsums) { E->lsum_n = 0; (void)hipMemsetAsync(E->d_lsums, 0, (size_t)E->lsum_cap * 8, st); }
+  vit_sums();
 
   // ln: 0 plain; 1 consumer of the folded LayerNorm (qkv, fc1); 2 producer (proj, fc2: 16-bit copy + row statistics)
   auto dense = [&](const void* A, int a_fp32, const std::string& wkey, int N, int K, void* C, int c_fp32, const float* bias,
@@ -1032,14 +1053,19 @@ int Run::forward(const void* x, void* y, void* y2) {
     if (!lf) chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
     dense(A(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, A(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0, lf ? 1 : 0,
           lf ? E->f(p + "attn.qkv.lnsum") : nullptr);
+    vit_sums();
     chk(launch_attention(dt, A(E->QKV), A(E->AO), B, S, N_HEADS, E->pl, st), "attention", 1);
+    vit_sums();
     exec_macs += 2.0 * N_HEADS * (double)S * S * 64;
     cat_macs[1] += 2.0 * N_HEADS * (double)S * S * 64;
     dense(A(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1, lf ? 2 : 0);
+    vit_sums();
     if (!lf) chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln2", 2);
     dense(A(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, A(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0, lf ? 1 : 0,
           lf ? E->f(p + "mlp.fc1.lnsum") : nullptr);
+    vit_sums();
     dense(A(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1, lf ? 2 : 0);
+    vit_sums();
     {
       char nm[16];
       snprintf(nm, sizeof nm, "blk%d", l);
@@ -1137,8 +1163,8 @@ int Run::forward(const void* x, void* y, void* y2) {
   if (E->head_fused(conv2_x3)) {
     // x2 upsample + conv 128->32 + ReLU + conv 1x1 + ReLU in one launch (head.hip): the 37.7 MB/image up-sampled map
     // and the 32-channel map never reach memory.  Not with a 3-MFMA conv2, and not while stage taps are recorded ("h1").
-    chk(launch_head_tail(mx ? MODE_FP16 : dt, A(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"), E->f(oc + "4.weight"),
-                         E->f(oc + "4.bias"), yout, io, B, h2, w2, ch, E->cfg.non_negative, st),
+    chk(launch_head_tail(conv2_x3 ? MODE_FP16X3 : (mx ? MODE_FP16 : dt), A(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"),
+                         E->f(oc + "4.weight"), E->f(oc + "4.bias"), yout, io, B, h2, w2, ch, E->cfg.non_negative, st, E->pl),
         "head.tail", 0);
     exec_macs += (double)Hi * Wi * 32 * 1152;
     cat_macs[0] += (double)Hi * Wi * 32 * (1152 + ch);
@@ -1708,10 +1734,22 @@ int dptx_op_gemm(int32_t dtype, const void* A, const void* W, const float* bias,
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
+// dense GEMM with the LayerNorm fold's CONSUMER epilogue (tools/gpu/r4_micro.py, tests): C = act((A W^T - mu colsum) rstd + bias),
+// (mu, rstd) of row m from the (sum, sum of squares) records ln_stats[m][0 .. ln_nblk) (row stride 8 records)
+int dptx_op_gemm_ln(int32_t dtype, const void* A, const void* W, const float* bias, void* C, int32_t M, int32_t N, int32_t K,
+                    int32_t act, const float* ln_stats, const float* ln_colsum, int32_t ln_nblk, float ln_eps, void* stream) {
+  GemmParams p;
+  gemm_params_dense(p, M, N, K);
+  p.A = A; p.W = W; p.C = C; p.bias = bias; p.act = act; p.planes = g_op_planes;
+  p.ln_stats = ln_stats; p.ln_colsum = ln_colsum; p.ln_nblk = ln_nblk; p.ln_eps = ln_eps; p.ln_inv_dim = 1.0f / (float)K;
+  return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
 int dptx_op_head_tail(int32_t dtype, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4, float* y,
                       int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t relu_out, void* stream) {
-  return launch_head_tail(dtype, H0, W2, b2, w4, b4, y, DPTX_IO_FP32, B, Hs, Ws, C, relu_out, (hipStream_t)stream) == hipSuccess ? DPTX_OK
-                                                                                                                : DPTX_E_HIP;
+  return launch_head_tail(dtype, H0, W2, b2, w4, b4, y, DPTX_IO_FP32, B, Hs, Ws, C, relu_out, (hipStream_t)stream, g_op_planes) == hipSuccess
+             ? DPTX_OK
+             : DPTX_E_HIP;
 }
 
 int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias, const void* R, void* Y, int32_t B, int32_t H,
@@ -1854,6 +1892,17 @@ int dptx_debug_arena_checksums(dptx_handle h, void* out_dev, int32_t capacity, v
         HIPCHK(h, launch_checksum(base, end - off, (unsigned long long*)out_dev + ((size_t)pl * regions + r) * nbuf + order[k].second, st));
       }
   return total;
+}
+
+// debug: word sums of {lnst, Hn, QKV, AO, F1} after every launch of the ViT blocks of the following single-stream forwards go to
+// dev_buf[launch * 5 + buffer] (uint64; launch 0 = after the cls rows, then qkv / attention / proj / fc1 / fc2 per block);
+// NULL switches it off.  The first entry that differs between two forwards of one input names the launch whose output differs.
+int dptx_debug_set_launch_sums(dptx_handle h, void* dev_buf, int32_t capacity) {
+  if (!h) return DPTX_E_INVALID;
+  h->d_lsums = (unsigned long long*)dev_buf;
+  h->lsum_cap = dev_buf ? capacity : 0;
+  h->lsum_n = 0;
+  return DPTX_OK;
 }
 
 int dptx_debug_set_trace(void* dev_buf) {

@@ -52,6 +52,30 @@ __device__ __forceinline__ int row_div(int m, int d, float rcp, bool big, int& r
   return q;
 }
 
+// (mu, rstd) of a token row from its (sum, sum of squares): var = E[x^2] - mu^2 in double -- the subtraction is where the bits go
+__device__ __forceinline__ float2 ln_mu_rstd(float sm, float sq, float inv_dim, float eps) {
+  const float mu = sm * inv_dim;
+  const float var = (float)((double)sq * (double)inv_dim - (double)mu * (double)mu);
+  return make_float2(mu, __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + eps));
+}
+
+// LayerNorm fold, consumer side: y = (acc - mu * colsum) * rstd + bias as two fused multiply-adds -- every kernel form that can
+// serve a layer rounds identically -- and as SCALAR v_fma_f32.  Left to itself hipcc pairs the elements into
+// v_pk_fma_f32 ... op_sel:[0,1,0]: both lanes of the packed op take rstd from the HIGH dword of the (mu, rstd) register pair
+// the table entry was loaded into.  On MI355X that form returned `bias` -- a product of zero -- in the LOW lane for work-items
+// 48..63 of a wave, a few times per thousand launches, whenever the stem convolution of ANOTHER stream shared the CU
+// (tools/gpu/r4_micro.py reproduces it in seconds: 224-445 of 2400 launches with the packed form, 0 of 2400 with this one;
+// operands recorded in the kernel were right).  It was round 3's "nondeterminism" of the multi-stream forward.
+// The empty asm keeps the SLP vectoriser from pairing the elements; tests/test_build_quality.py checks the compiled ISA for
+// packed fp32 operations whose low lane reads a high dword.
+__device__ __forceinline__ float ln_fold_fma(float acc, float mu, float rstd, float colsum, float bias) {
+  float t = fmaf(-mu, colsum, acc);
+  asm volatile("" : "+v"(t));
+  t = fmaf(t, rstd, bias);
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 // ----------------------------------------------------------------------------- shared pieces
 template <int DT, int TM, int TN, bool RELU_A, int PL = 1, int HK = BK / 16>
 __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_lo, int b_lo, int wm, int wn, int lr, int lh,
@@ -306,10 +330,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
       const float4 r0 = st[0], r1_ = st[1], r2_ = st[2], r3_ = st[3];
       const float sm = (r0.x + r0.z) + (r1_.x + r1_.z) + ((r2_.x + r2_.z) + (all8 ? r3_.x + r3_.z : 0.f));
       const float sq = (r0.y + r0.w) + (r1_.y + r1_.w) + ((r2_.y + r2_.w) + (all8 ? r3_.y + r3_.w : 0.f));
-      const float mu = sm * p.ln_inv_dim;
-      // E[x^2] - mu^2 in double: the subtraction is where the bits would go
-      const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
-      lnrow[r] = make_float2(mu, __builtin_amdgcn_rsqf(fmaxf((float)var, 0.f) + p.ln_eps));
+      lnrow[r] = ln_mu_rstd(sm, sq, p.ln_inv_dim, p.ln_eps);
     }
     if (WP) __syncthreads();  // the only block barrier of the wave-private epilogue
   }
@@ -448,8 +469,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             // compiler fuses "x * rstd + bias" at one call site and not at another (1-ulp differences, which the
             // batch-invariance test caught)
             const float2 ms = lnrow[ln_R[it]];  // (mu, rstd) of this row: one LDS broadcast read per 32 threads
+#ifdef DPTX_LN_PACKED_FMA   /* round 3's form, for tools/gpu/r4_micro.py: hipcc turns this into v_pk_fma_f32 ... op_sel:[0,1,0] */
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaf(fmaf(-ms.x, ln_c[e], v[e]), ms.y, bias_c[e]);
+#else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ln_fold_fma(v[e], ms.x, ms.y, ln_c[e], bias_c[e]);
+#endif
           } else if (bpi) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(bb[it][0][e]); v[4 + e] += __uint_as_float(bb[it][1][e]); }
@@ -789,9 +815,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem,
     // same association as the staged epilogue's table: the two forms give bit-identical results
     const float sm = (r0.x + r0.z) + (r1_.x + r1_.z) + ((r2_.x + r2_.z) + (all8 ? r3_.x + r3_.z : 0.f));
     const float sq = (r0.y + r0.w) + (r1_.y + r1_.w) + ((r2_.y + r2_.w) + (all8 ? r3_.y + r3_.w : 0.f));
-    const float mu = sm * p.ln_inv_dim;
-    const double var = (double)sq * (double)p.ln_inv_dim - (double)mu * (double)mu;
-    lnrow[r] = make_float2(mu, __builtin_amdgcn_rsqf(fmaxf((float)var, 0.f) + p.ln_eps));
+    lnrow[r] = ln_mu_rstd(sm, sq, p.ln_inv_dim, p.ln_eps);
   }
   // the next tile's first k-tile (DMA issued by the caller) lands before this tile's first store is issued: stores count
   // in vmcnt, a vmcnt(0) after them would wait for the tile to reach memory
@@ -826,7 +850,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem,
           const float4 c0 = *(const float4*)(scol + col), c1 = *(const float4*)(scol + col + 4);
           const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaf(fmaf(-ms.x, cc[e], v[e]), ms.y, bb[e]);
+          for (int e = 0; e < 8; ++e) v[e] = ln_fold_fma(v[e], ms.x, ms.y, cc[e], bb[e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bb[e];

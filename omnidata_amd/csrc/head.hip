@@ -229,9 +229,233 @@ __global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same tail for the hi/lo-plane modes (fp16x3 / bf16x3 and the head of the parity mode "mixed"): H0 and W2 are plane pairs
+// (lo = x - hi at a fixed distance) and every product is three MFMAs (lo*hi + hi*lo + hi*hi).  Unfused this stretch is 3 ms of
+// the 20.8 ms parity-mode forward at B = 32 (head.up moves four 37.7 MB/image planes, the 3-MFMA conv with N = 32 runs at
+// 520 TFLOP/s-equivalent, head.out re-reads two planes): profiles/r04_experiments.md.
+//
+// Two planes of the 10 x 34 window (174 KB) and of the weights (147 KB) do not fit 160 KB of LDS, so the K axis is split into
+// two CHANNEL HALVES that are processed one after the other into the same accumulators: per half the block holds
+//   W  [plane][tap][n = 32][64 ch]   = 73 728 B   (LDS-DMA from L2 per tile and half: lane-linear 8-row pieces, XOR swizzle on
+//                                                  the SOURCE chunk as in gemm_impl.h -- conflict-free ds_read_b128)
+//   P  [plane][10 rows][34 cols][64 ch] = 87 040 B (built by 272 of the 512 threads: a thread owns one window column and eight
+//                                                  channels, fed by 6 x 2 x 2 source vectors)
+// and runs 36 k-steps x 3 MFMAs per wave (wave w = output row w).  The weights are re-streamed per tile (147 KB per 8 x 32
+// pixels: ~21 MB per CU and forward, under the MFMA time).  The 32-channel map stays in fp32 registers: bias + ReLU + the 1x1
+// projection + ReLU as in the single-plane kernel; the unfused path rounds it to a hi/lo pair first (test bound:
+// tests/test_gpu_mixed.py).  The up-sampled window is bit-identical to upsample2x_kernel<DT, 2> (same blend, same split).
+constexpr int HX_WPL = 9 * 32 * 128;            // bytes of one weight plane of one channel half: [tap][n][8 chunks x 16 B]
+constexpr int HX_PPL = HT_PR * HT_PC * 128;     // bytes of one window plane of one channel half
+constexpr size_t HX_SMEM = 2 * HX_WPL + 2 * HX_PPL + HT_CONST_FLOATS * 4;
+static_assert(HX_SMEM <= 160 * 1024, "one block per CU");
+
+template <int DT>
+__device__ __forceinline__ void hblend2(const u32x4_t (&s0)[2], const u32x4_t (&s1)[2], float lx0, float lx1, float (&t)[8]) {
+  float a[8], b[8];
+  unpack8x<DT, 2>(s0[0], s0[1], a);   // hi + lo
+  unpack8x<DT, 2>(s1[0], s1[1], b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = __fmaf_rn(lx1, b[e], __fmul_rn(lx0, a[e]));
+}
+
+constexpr int HX_THREADS = 512;   // 8 waves = 2 per SIMD: 256 registers per work-item (the prefetched source vectors need them)
+
+template <int DT>
+__global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t* __restrict__ H0, const uint16_t* __restrict__ W2,
+                                                                  const float* __restrict__ b2, const float* __restrict__ w4,
+                                                                  const float* __restrict__ b4, void* __restrict__ y, int io, int B,
+                                                                  int Hs, int Ws, int C, int relu_out, int ntiles, long long plane,
+                                                                  long long wplane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;                      // [2][9][32][128 B]
+  char* P = smem + 2 * HX_WPL;          // [2][10][34][128 B]
+  float* cst = (float*)(smem + 2 * HX_WPL + 2 * HX_PPL);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int Ho = 2 * Hs, Wo = 2 * Ws;
+  const int tiles_x = Wo / 32, tiles_y = Ho / 8, tpi = tiles_x * tiles_y;
+  const float ry = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+  const float rx = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+
+  if (tid < 32) cst[tid] = b2[tid];
+  if (tid < 32 * C) cst[32 + tid] = w4[tid];
+  if (tid < C) cst[128 + tid] = b4[tid];
+
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int t_beg = blockIdx.x * per, t_end = min(t_beg + per, ntiles);
+
+  // window builder: thread (wx = column 0..33, wch = channel chunk 0..7 of the half) owns its column of all ten window rows
+  const bool builder = tid < HT_PC * 8;
+  const int wx = tid >> 3, wch = tid & 7;
+
+  // weight DMA: wave-instruction q (0..71) moves the 1 KB piece [plane = q / 36][rows 8 (q % 36) .. + 7 of (tap, n)][8 chunks];
+  // lane l -> row r = 8 (q % 36) + l / 8 (tap = r / 32, n = r % 32), LDS chunk l % 8 holds SOURCE chunk (l % 8) ^ ((n >> 1) & 7)
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(W2), 0, (int)((wplane + 32 * 1152) * 2), 0x00020000);
+  auto issue_w = [&](int half) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int q = wave * 9 + k;
+      const int pl = q / 36, r = 8 * (q % 36) + (lane >> 3);
+      const int tap = r >> 5, n = r & 31;
+      const int sch = (lane & 7) ^ ((n >> 1) & 7);
+      const unsigned off = (unsigned)(((long long)pl * wplane + n * 1152 + tap * 128 + half * 64 + sch * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(Wl + q * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  u32x4_t S[6][2][2];  // [source row][x0 / x1][plane]
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int t, int half) {
+    const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int ox = tx * 32 - 1 + wx;
+    const bool vx = builder && ox >= 0 && ox < Wo;
+    const float sx = rx * (float)(vx ? ox : 0);
+    const int x0 = (int)sx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const int ybase = (int)(ry * (float)max(ty * 8 - 1, 0));
+    const uint16_t* img = H0 + (long long)b * Hs * Ws * 128 + half * 64 + wch * 8;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int row = min(ybase + j, Hs - 1);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        S[j][0][pl] = vx ? *(const u32x4_t*)(img + pl * plane + ((long long)row * Ws + x0) * 128) : zero4;
+        S[j][1][pl] = vx ? *(const u32x4_t*)(img + pl * plane + ((long long)row * Ws + x1) * 128) : zero4;
+      }
+    }
+  };
+
+  __syncthreads();
+
+  for (int t = t_beg; t < t_end; ++t) {
+    const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 32;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      // ---- phase A: this half's weights by DMA, its window from the source vectors (fetched here: 24 vectors per builder next
+      // to the MFMA phase's registers would spill, so their latency is exposed once per half -- ~10 % of the kernel)
+      issue_w(half);
+      fetch(t, half);
+      if (builder) {
+        const int ox = ox0 - 1 + wx;
+        const bool vx = ox >= 0 && ox < Wo;
+        const float sx = rx * (float)(vx ? ox : 0);
+        const int x0 = (int)sx;
+        const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+        const int ybase = (int)(ry * (float)max(oy0 - 1, 0));
+        float T[6][8];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          hblend2<DT>(S[j][0], S[j][1], lx0, lx1, T[j]);
+          __builtin_amdgcn_sched_barrier(0);   // row by row: the source vectors die as the blended rows are formed (registers)
+        }
+        for (int r = 0; r < HT_PR; ++r) {
+          const int oy = oy0 - 1 + r;
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+          if (vx && oy >= 0 && oy < Ho) {
+            const float sy = ry * (float)oy;
+            const int y0 = (int)sy;
+            const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+            switch (y0 - ybase) {  // uniform over the block; slot j + 1 holds row min(y0 + 1, Hs - 1) = ATen's y1
+#define HX_VB(J) _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[J + 1][e], __fmul_rn(ly0, T[J][e]))
+              case 0: HX_VB(0); break;
+              case 1: HX_VB(1); break;
+              case 2: HX_VB(2); break;
+              case 3: HX_VB(3); break;
+              default: HX_VB(4); break;
+#undef HX_VB
+            }
+          }
+          // hi / lo split exactly as store8f<DT, 2> (zero stays zero in both planes: the conv's padding)
+          const uint4 hi = pack8<DT>(o);
+          float hf[8], lf[8];
+          unpack8<DT>(hi, hf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) lf[e] = o[e] - hf[e];
+          const uint4 lo = pack8<DT>(lf);
+          const int idx = r * HT_PC + wx;
+          char* dst = P + idx * 128 + ((wch ^ ((idx >> 1) & 7)) << 4);
+          *(u32x4_t*)dst = u32x4_t{hi.x, hi.y, hi.z, hi.w};
+          *(u32x4_t*)(dst + HX_PPL) = u32x4_t{lo.x, lo.y, lo.z, lo.w};
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight pieces of this wave have landed (the barrier publishes them)
+      __syncthreads();
+
+      // ---- phase B: 36 k-steps x (hi*lo + lo*hi + hi*hi); transposed: acc[r] = channel (r&3)+8(r>>2)+4 lh of pixel lr
+      {
+        u32x4_t wf[2][2], pf[2][2];  // [set][plane]
+        // (tap, cb): channels 16 cb .. 16 cb + 15 of the half at window pixel (wave + ky, lr + kx)
+        auto read_ks = [&](int tap, int cb, u32x4_t (&w)[2], u32x4_t (&q)[2]) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const int chunk = 2 * cb + lh;
+          const char* wr = Wl + (tap * 32 + lr) * 128 + ((chunk ^ ((lr >> 1) & 7)) << 4);
+          const int idx = (wave + ky) * HT_PC + lr + kx;
+          const char* pr = P + idx * 128 + ((chunk ^ ((idx >> 1) & 7)) << 4);
+          w[0] = *(const u32x4_t*)wr;
+          w[1] = *(const u32x4_t*)(wr + HX_WPL);
+          q[0] = *(const u32x4_t*)pr;
+          q[1] = *(const u32x4_t*)(pr + HX_PPL);
+        };
+        // the tap loop stays a loop (fully unrolled, hipcc keeps the 36 + 36 swizzled fragment addresses live across the tile
+        // loop and spills); the reads still run one k-step ahead of the MFMAs, across the tap boundary as well
+        read_ks(0, 0, wf[0], pf[0]);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            if (cb < 3) read_ks(tap, cb + 1, wf[(cb + 1) & 1], pf[(cb + 1) & 1]);
+            else if (tap + 1 < 9) read_ks(tap + 1, 0, wf[0], pf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = T16<DT>::mfma32(wf[cb & 1][0], pf[cb & 1][1], acc);   // w_hi * a_lo
+            acc = T16<DT>::mfma32(wf[cb & 1][1], pf[cb & 1][0], acc);   // w_lo * a_hi
+            acc = T16<DT>::mfma32(wf[cb & 1][0], pf[cb & 1][0], acc);   // w_hi * a_hi
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (half == 1) {
+          float h[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 bb = *(const float4*)(cst + 8 * q + 4 * lh);
+            h[4 * q + 0] = fmaxf(acc[4 * q + 0] + bb.x, 0.f);
+            h[4 * q + 1] = fmaxf(acc[4 * q + 1] + bb.y, 0.f);
+            h[4 * q + 2] = fmaxf(acc[4 * q + 2] + bb.z, 0.f);
+            h[4 * q + 3] = fmaxf(acc[4 * q + 3] + bb.w, 0.f);
+          }
+          const int oy = oy0 + wave;
+          for (int c = 0; c < C; ++c) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 ww = *(const float4*)(cst + 32 + c * 32 + 8 * q + 4 * lh);
+              sacc += ww.x * h[4 * q + 0] + ww.y * h[4 * q + 1] + ww.z * h[4 * q + 2] + ww.w * h[4 * q + 3];
+            }
+            sacc += __shfl_xor(sacc, 32);
+            sacc += cst[128 + c];
+            if (relu_out) sacc = fmaxf(sacc, 0.f);
+            if ((c & 1) == lh) io_store(y, (((long long)b * C + c) * Ho + oy) * Wo + ox0 + lr, sacc, io);
+          }
+        }
+      }
+      __syncthreads();  // weights and window are rebuilt for the next half
+    }
+  }
+#endif
+}
+
 hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
-                            void* y, int io, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream) {
-  if (mode_is_x3(mode) || C < 1 || C > 3 || (2 * Hs) % 8 != 0 || (2 * Ws) % 32 != 0) return hipErrorInvalidValue;
+                            void* y, int io, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream, Planes pl) {
+  if (C < 1 || C > 3 || (2 * Hs) % 8 != 0 || (2 * Ws) % 32 != 0) return hipErrorInvalidValue;
   const int ntiles = B * ((2 * Hs) / 8) * ((2 * Ws) / 32);
   static int cus = 0;
   if (cus == 0) {
@@ -241,6 +465,16 @@ hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const floa
     if (cus <= 0) cus = 256;
   }
   const int grid = ntiles < cus ? ntiles : cus;
+  if (mode_is_x3(mode)) {   // hi / lo planes, three MFMAs per product (head_tail_x3_kernel)
+    // fp16 planes only (the parity mode "mixed" and fp16x3): the bf16 conversions of the window builder need more registers
+    // than two waves per SIMD have (92 bytes of scratch); bf16x3 -- the range fallback -- keeps the three-launch tail
+    if (mode != MODE_FP16X3 || pl.act == 0 || pl.w == 0 || (pl.w + 32 * 1152) * 2 >= (1ll << 31)) return hipErrorInvalidValue;
+    auto k = head_tail_x3_kernel<DT_FP16>;
+    ensure_dyn_smem((const void*)k, HX_SMEM);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(HX_THREADS), HX_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, io, B,
+                       Hs, Ws, C, relu_out, ntiles, pl.act, pl.w);
+    return hipGetLastError();
+  }
   if (mode == MODE_BF16) {
     auto k = head_tail_kernel<DT_BF16>;
     ensure_dyn_smem((const void*)k, HT_SMEM);

@@ -141,9 +141,10 @@ hipError_t launch_head_out(int mode, const void* X, const float* w, const float*
                            int Cout, int relu, Planes pl, hipStream_t stream);
 
 // X[b*577] = cls + pos[0]  (fp32 token stream)
-// fused tail of the head: x2 bilinear -> conv3x3 128->32 -> ReLU -> conv1x1 32->C -> ReLU (head.hip; not in bf16x3 mode)
+// fused tail of the head: x2 bilinear -> conv3x3 128->32 -> ReLU -> conv1x1 32->C -> ReLU (head.hip)
+// (hi / lo-plane modes: head_tail_x3_kernel, three MFMAs per product; `pl` = the plane distances of H0 and W2)
 hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4,
-                            void* y, int io, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream);
+                            void* y, int io, int B, int Hs, int Ws, int C, int relu_out, hipStream_t stream, Planes pl = Planes{0, 0});
 hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, int gw, int C, hipStream_t stream);
 // X16 / stats (optional, LayerNorm fold): 16-bit copy of the rows and their (sum, sum of squares) per 128-column block; X may
 // be null (16-bit token stream: no fp32 copy)

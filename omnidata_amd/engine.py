@@ -85,9 +85,11 @@ ABI = [
     ("dptx_debug_arena_read", C.c_int, [_vp, _vp, _sz, _sz]),
     ("dptx_debug_arena_layout", C.c_int, [_vp, C.c_char_p, _sz]),
     ("dptx_debug_arena_checksums", C.c_int, [_vp, _vp, _i32, _vp]),
+    ("dptx_debug_set_launch_sums", C.c_int, [_vp, _vp, _i32]),
     ("dptx_op_conv_fp8", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [C.c_float, _vp]),
     ("dptx_op_conv_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 12 + [C.c_float, _vp, _vp]),
     ("dptx_op_upsample2x", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    ("dptx_op_gemm_ln", C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, C.c_float, _vp]),
     ("dptx_op_head_tail", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
 ]
 
