@@ -239,8 +239,8 @@ __global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* _
 // two CHANNEL HALVES that are processed one after the other into the same accumulators: per half the block holds
 //   W  [plane][tap][n = 32][64 ch]   = 73 728 B   (LDS-DMA from L2 per tile and half: lane-linear 8-row pieces, XOR swizzle on
 //                                                  the SOURCE chunk as in gemm_impl.h -- conflict-free ds_read_b128)
-//   P  [plane][10 rows][34 cols][64 ch] = 87 040 B (built by 272 of the 512 threads: a thread owns one window column and eight
-//                                                  channels, fed by 6 x 2 x 2 source vectors)
+//   P  [plane][10 rows][34 cols][64 ch] = 87 040 B (a thread builds five window rows of one column and eight channels from
+//                                                  4 x 2 x 2 source vectors)
 // and runs 36 k-steps x 3 MFMAs per wave (wave w = output row w).  The weights are re-streamed per tile (147 KB per 8 x 32
 // pixels: ~21 MB per CU and forward, under the MFMA time).  The 32-channel map stays in fp32 registers: bias + ReLU + the 1x1
 // projection + ReLU as in the single-plane kernel; the unfused path rounds it to a hi/lo pair first (test bound:
@@ -288,9 +288,10 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;
   const int t_beg = blockIdx.x * per, t_end = min(t_beg + per, ntiles);
 
-  // window builder: thread (wx = column 0..33, wch = channel chunk 0..7 of the half) owns its column of all ten window rows
-  const bool builder = tid < HT_PC * 8;
-  const int wx = tid >> 3, wch = tid & 7;
+  // window builder: an ITEM is (window column, 8-channel chunk of the half, row half): five window rows of one column from
+  // four source rows.  The 32 inner columns (1..32) give exactly 512 items -- one per thread; the two halo columns (0 and 33:
+  // 32 items) are built by the first 32 threads in a second pass.
+  const int wx_main = 1 + ((tid >> 3) & 31), wch = tid & 7, rh_main = tid >> 8;
 
   // weight DMA: wave-instruction q (0..71) moves the 1 KB piece [plane = q / 36][rows 8 (q % 36) .. + 7 of (tap, n)][8 chunks];
   // lane l -> row r = 8 (q % 36) + l / 8 (tap = r / 32, n = r % 32), LDS chunk l % 8 holds SOURCE chunk (l % 8) ^ ((n >> 1) & 7)
@@ -307,24 +308,74 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
     }
   };
 
-  u32x4_t S[6][2][2];  // [source row][x0 / x1][plane]
+  typedef u32x4_t SrcVecs[4][2][2];  // [source row][x0 / x1][plane]
   const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-  auto fetch = [&](int t, int half) {
+  auto fetch = [&](int t, int half, int wx, int rh, SrcVecs& S) {
     const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int ox = tx * 32 - 1 + wx;
-    const bool vx = builder && ox >= 0 && ox < Wo;
+    const bool vx = ox >= 0 && ox < Wo;
     const float sx = rx * (float)(vx ? ox : 0);
     const int x0 = (int)sx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-    const int ybase = (int)(ry * (float)max(ty * 8 - 1, 0));
+    const int ybase = (int)(ry * (float)max(ty * 8 - 1 + 5 * rh, 0));
     const uint16_t* img = H0 + (long long)b * Hs * Ws * 128 + half * 64 + wch * 8;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const int row = min(ybase + j, Hs - 1);
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
         S[j][0][pl] = vx ? *(const u32x4_t*)(img + pl * plane + ((long long)row * Ws + x0) * 128) : zero4;
         S[j][1][pl] = vx ? *(const u32x4_t*)(img + pl * plane + ((long long)row * Ws + x1) * 128) : zero4;
       }
+    }
+  };
+  // five window rows (5 rh .. 5 rh + 4) of column wx into both planes of the window (zero outside the image: the conv's padding)
+  auto build = [&](int oy0, int ox0, int wx, int rh, const SrcVecs& S) {
+    const int ox = ox0 - 1 + wx;
+    const bool vx = ox >= 0 && ox < Wo;
+    const float sx = rx * (float)(vx ? ox : 0);
+    const int x0 = (int)sx;
+    const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+    const int ybase = (int)(ry * (float)max(oy0 - 1 + 5 * rh, 0));
+    float T[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hblend2<DT>(S[j][0], S[j][1], lx0, lx1, T[j]);
+      __builtin_amdgcn_sched_barrier(0);   // row by row (registers: interleaved, the five rows below alone take ~150)
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int r = 5 * rh + k, oy = oy0 - 1 + r;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      if (vx && oy >= 0 && oy < Ho) {
+        const float sy = ry * (float)oy;
+        const int y0 = (int)sy;
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        const int j0 = y0 - ybase;  // 0..2 (uniform over the threads of a row half); slot j0 + 1 holds row min(y0 + 1, Hs - 1) = ATen's y1
+        if (j0 == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[1][e], __fmul_rn(ly0, T[0][e]));
+        } else if (j0 == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[2][e], __fmul_rn(ly0, T[1][e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[3][e], __fmul_rn(ly0, T[2][e]));
+        }
+      }
+      // hi / lo split exactly as store8f<DT, 2>
+      const uint4 hi = pack8<DT>(o);
+      float hf[8], lf[8];
+      unpack8<DT>(hi, hf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lf[e] = o[e] - hf[e];
+      const uint4 lo = pack8<DT>(lf);
+      const int idx = r * HT_PC + wx;
+      char* dst = P + idx * 128 + ((wch ^ ((idx >> 1) & 7)) << 4);
+      *(u32x4_t*)dst = u32x4_t{hi.x, hi.y, hi.z, hi.w};
+      *(u32x4_t*)(dst + HX_PPL) = u32x4_t{lo.x, lo.y, lo.z, lo.w};
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -339,54 +390,19 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
 
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-      // ---- phase A: this half's weights by DMA, its window from the source vectors (fetched here: 24 vectors per builder next
-      // to the MFMA phase's registers would spill, so their latency is exposed once per half -- ~10 % of the kernel)
+      // ---- phase A: this half's weights by DMA, its window from the source vectors
       issue_w(half);
-      fetch(t, half);
-      if (builder) {
-        const int ox = ox0 - 1 + wx;
-        const bool vx = ox >= 0 && ox < Wo;
-        const float sx = rx * (float)(vx ? ox : 0);
-        const int x0 = (int)sx;
-        const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-        const int ybase = (int)(ry * (float)max(oy0 - 1, 0));
-        float T[6][8];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          hblend2<DT>(S[j][0], S[j][1], lx0, lx1, T[j]);
-          __builtin_amdgcn_sched_barrier(0);   // row by row: the source vectors die as the blended rows are formed (registers)
-        }
-        for (int r = 0; r < HT_PR; ++r) {
-          const int oy = oy0 - 1 + r;
-          float o[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = 0.f;
-          if (vx && oy >= 0 && oy < Ho) {
-            const float sy = ry * (float)oy;
-            const int y0 = (int)sy;
-            const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
-            switch (y0 - ybase) {  // uniform over the block; slot j + 1 holds row min(y0 + 1, Hs - 1) = ATen's y1
-#define HX_VB(J) _Pragma("unroll") for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[J + 1][e], __fmul_rn(ly0, T[J][e]))
-              case 0: HX_VB(0); break;
-              case 1: HX_VB(1); break;
-              case 2: HX_VB(2); break;
-              case 3: HX_VB(3); break;
-              default: HX_VB(4); break;
-#undef HX_VB
-            }
-          }
-          // hi / lo split exactly as store8f<DT, 2> (zero stays zero in both planes: the conv's padding)
-          const uint4 hi = pack8<DT>(o);
-          float hf[8], lf[8];
-          unpack8<DT>(hi, hf);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) lf[e] = o[e] - hf[e];
-          const uint4 lo = pack8<DT>(lf);
-          const int idx = r * HT_PC + wx;
-          char* dst = P + idx * 128 + ((wch ^ ((idx >> 1) & 7)) << 4);
-          *(u32x4_t*)dst = u32x4_t{hi.x, hi.y, hi.z, hi.w};
-          *(u32x4_t*)(dst + HX_PPL) = u32x4_t{lo.x, lo.y, lo.z, lo.w};
-        }
+      {
+        // (the source vectors are fetched here, not one half ahead: 64 more registers across the MFMA phase spill)
+        SrcVecs S;
+        fetch(t, half, wx_main, rh_main, S);
+        build(oy0, ox0, wx_main, rh_main, S);
+      }
+      if (tid < 32) {   // the two halo columns
+        SrcVecs H;
+        const int hx = (tid >> 3) & 1 ? HT_PC - 1 : 0, hrh = tid >> 4;
+        fetch(t, half, hx, hrh, H);
+        build(oy0, ox0, hx, hrh, H);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight pieces of this wave have landed (the barrier publishes them)
       __syncthreads();

@@ -60,6 +60,43 @@ def test_fp16x3_gemm(M, N, K):
         ar.release()
 
 
+@pytest.mark.parametrize("B,Hs,Ws,C,relu", [(2, 96, 96, 3, 1), (1, 192, 192, 1, 1), (3, 64, 80, 3, 0), (1, 16, 16, 1, 1)])
+def test_fp16x3_fused_head_tail(B, Hs, Ws, C, relu):
+    """head_tail_x3_kernel (head.hip): x2 bilinear (align_corners) -> conv3x3 128->32 -> ReLU -> conv1x1 32->C -> ReLU on hi/lo
+    fp16 planes with three MFMAs per product, against the chain in fp64 torch on the values the planes hold; the up-sampled
+    map is the hi/lo split of the fp32 blend, as upsample2x_kernel<fp16, 2> writes it."""
+    lib = load_library()
+    ar = PlaneArena(B * Hs * Ws * 128 + 32 * 9 * 128 + B * 4 * Hs * Ws * 128 + 8192, dtype=torch.float16)
+    try:
+        H0 = ar.put(g(B, Hs, Ws, 128, seed=21))
+        W2 = ar.put(g(32, 3, 3, 128, scale=1152 ** -0.5, seed=22))
+        b2 = torch.randn(32, device=DEV) * 0.3
+        w4 = torch.randn(C, 32, device=DEV) * 0.3
+        b4 = torch.randn(C, device=DEV) * 0.2
+        y = torch.full((B, C, 2 * Hs, 2 * Ws), float("nan"), device=DEV)
+        assert lib.dptx_op_head_tail(F16X3, ptr(H0), ptr(W2), ptr(b2), ptr(w4), ptr(b4), ptr(y), B, Hs, Ws, C, relu, stream()) == 0
+        assert torch.isfinite(y).all()
+        # this library's own up-sampling of the plane pair (bit-identical window), then fp64
+        U = ar.empty(B, 2 * Hs, 2 * Ws, 128)
+        assert lib.dptx_op_upsample2x(F16X3, ptr(H0), ptr(U), B, Hs, Ws, 128, stream()) == 0
+        h = F.relu(F.conv2d(ar.value(U).permute(0, 3, 1, 2), ar.value(W2).permute(0, 3, 1, 2), b2.double(), padding=1))
+        ref = F.conv2d(h, w4.double().view(C, 32, 1, 1), b4.double())
+        if relu:
+            ref = F.relu(ref)
+        err = rel_err(y, ref)
+        print(f"\n[fp16x3 fused head tail B={B} {Hs}x{Ws} C={C}] rel err vs fp64 {err:.2e}")
+        assert err < TOL
+        # and within fp32 interpolation rounding of torch's own bilinear on the exact values
+        up = F.interpolate(ar.value(H0).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+        h = F.relu(F.conv2d(up, ar.value(W2).permute(0, 3, 1, 2), b2.double(), padding=1))
+        ref2 = F.conv2d(h, w4.double().view(C, 32, 1, 1), b4.double())
+        if relu:
+            ref2 = F.relu(ref2)
+        assert rel_err(y, ref2) < 2 * TOL
+    finally:
+        ar.release()
+
+
 @pytest.mark.parametrize("case", [(2, 24, 256, 256, 3, 1, 1, 24, 1, 1), (3, 48, 128, 128, 3, 2, 0, 24, 0, 0)])
 def test_fp16x3_conv(case):
     from tests.test_gpu_ops import conv_ref
