@@ -18,6 +18,8 @@
 // k order = (tap, channel), the implicit-GEMM's: the fp32 accumulation sequence is the unfused path's.
 // 576 threads: waves 0-7 own window columns 0..31 and the MFMA rows, wave 8 owns the two halo columns.
 // LDS 161.3 KB -> one block per CU; grid = min(tiles, CUs), each block walks a contiguous run of tiles.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -230,25 +232,31 @@ __global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same tail for the hi/lo-plane modes (fp16x3 / bf16x3 and the head of the parity mode "mixed"): H0 and W2 are plane pairs
-// (lo = x - hi at a fixed distance) and every product is three MFMAs (lo*hi + hi*lo + hi*hi).  Unfused this stretch is 3 ms of
+// The same tail for the hi/lo-plane modes (fp16x3 and the head of the parity mode "mixed"): H0 and W2 are plane pairs
+// (lo = x - hi at a fixed distance) and every product is three MFMAs (hi*lo + lo*hi + hi*hi).  Unfused this stretch is 3 ms of
 // the 20.8 ms parity-mode forward at B = 32 (head.up moves four 37.7 MB/image planes, the 3-MFMA conv with N = 32 runs at
 // 520 TFLOP/s-equivalent, head.out re-reads two planes): profiles/r04_experiments.md.
 //
 // Two planes of the 10 x 34 window (174 KB) and of the weights (147 KB) do not fit 160 KB of LDS, so the K axis is split into
-// two CHANNEL HALVES that are processed one after the other into the same accumulators: per half the block holds
-//   W  [plane][tap][n = 32][64 ch]   = 73 728 B   (LDS-DMA from L2 per tile and half: lane-linear 8-row pieces, XOR swizzle on
-//                                                  the SOURCE chunk as in gemm_impl.h -- conflict-free ds_read_b128)
-//   P  [plane][10 rows][34 cols][64 ch] = 87 040 B (a thread builds five window rows of one column and eight channels from
-//                                                  4 x 2 x 2 source vectors)
-// and runs 36 k-steps x 3 MFMAs per wave (wave w = output row w).  The weights are re-streamed per tile (147 KB per 8 x 32
-// pixels: ~21 MB per CU and forward, under the MFMA time).  The 32-channel map stays in fp32 registers: bias + ReLU + the 1x1
-// projection + ReLU as in the single-plane kernel; the unfused path rounds it to a hi/lo pair first (test bound:
-// tests/test_gpu_mixed.py).  The up-sampled window is bit-identical to upsample2x_kernel<DT, 2> (same blend, same split).
-constexpr int HX_WPL = 9 * 32 * 128;            // bytes of one weight plane of one channel half: [tap][n][8 chunks x 16 B]
-constexpr int HX_PPL = HT_PR * HT_PC * 128;     // bytes of one window plane of one channel half
-constexpr size_t HX_SMEM = 2 * HX_WPL + 2 * HX_PPL + HT_CONST_FLOATS * 4;
-static_assert(HX_SMEM <= 160 * 1024, "one block per CU");
+// four CHANNEL QUARTERS of 32 that are processed one after the other into the same accumulators.  Per quarter a block holds
+//   W  [plane][tap][n = 32][32 ch]        = 36 864 B  (LDS-DMA from L2 per tile and quarter: lane-linear 16-row pieces, XOR
+//                                                      swizzle on the SOURCE chunk -- conflict-free ds_read_b128 of 64-byte rows)
+//   P  [plane][10 rows][34 cols][32 ch]   = 43 520 B  (a thread builds five window rows of one column and eight channels from
+//                                                      4 x 2 x 2 source vectors)
+// = 78.5 KB, 256 threads: two blocks fit a CU.  A wave owns two output rows (the weight fragments are read once for both): 18
+// k-steps x 2 rows x 3 MFMAs per quarter.  Measured at B = 32 (tools/gpu/r4_headx3_bench.py, DPTX_HX_DBG ablations): 1.53 ms per
+// launch = window build 0.57 + MFMA phase 0.77 (0.47 at the MFMA peak) + weight DMA 0.04 + skeleton / stores 0.18 -- the phases
+// of the two blocks do NOT overlap (the same 1.5-1.7 ms as the first form of this kernel, one 161 KB block of 512 threads per
+// CU with channel halves; starting the second block half a period late changes nothing): what is left is a warp-specialised
+// form in which builder waves run ahead of MFMA waves through a double-buffered window.  The weights are re-streamed per tile (147 KB per 8 x 32 pixels,
+// ~21 MB per CU and forward out of L2).  The 32-channel map stays in fp32 registers: bias + ReLU + the 1x1 projection + ReLU
+// as in the single-plane kernel; the unfused path rounds it to a hi/lo pair first (bound: tests/test_gpu_mixed.py).  The
+// up-sampled window is bit-identical to upsample2x_kernel<DT, 2> (same blend, same split).
+constexpr int HX_THREADS = 256;
+constexpr int HX_WPL = 9 * 32 * 64;             // bytes of one weight plane of one channel quarter: [tap][n][4 chunks x 16 B]
+constexpr int HX_PPL = HT_PR * HT_PC * 64;      // bytes of one window plane of one channel quarter
+constexpr size_t HX_SMEM = 2 * HX_WPL + 2 * HX_PPL;   // 80 384 B: two blocks and 3 KB to spare (the head constants stay in memory)
+static_assert(2 * ((HX_SMEM + 1023) / 1024 * 1024) <= 160 * 1024, "two blocks per CU");
 
 template <int DT>
 __device__ __forceinline__ void hblend2(const u32x4_t (&s0)[2], const u32x4_t (&s1)[2], float lx0, float lx1, float (&t)[8]) {
@@ -259,19 +267,17 @@ __device__ __forceinline__ void hblend2(const u32x4_t (&s0)[2], const u32x4_t (&
   for (int e = 0; e < 8; ++e) t[e] = __fmaf_rn(lx1, b[e], __fmul_rn(lx0, a[e]));
 }
 
-constexpr int HX_THREADS = 512;   // 8 waves = 2 per SIMD: 256 registers per work-item (the prefetched source vectors need them)
-
 template <int DT>
-__global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t* __restrict__ H0, const uint16_t* __restrict__ W2,
-                                                                  const float* __restrict__ b2, const float* __restrict__ w4,
-                                                                  const float* __restrict__ b4, void* __restrict__ y, int io, int B,
-                                                                  int Hs, int Ws, int C, int relu_out, int ntiles, long long plane,
-                                                                  long long wplane) {
+__global__ __launch_bounds__(HX_THREADS, 2) void head_tail_x3_kernel(const uint16_t* __restrict__ H0, const uint16_t* __restrict__ W2,
+                                                                     const float* __restrict__ b2, const float* __restrict__ w4,
+                                                                     const float* __restrict__ b4, void* __restrict__ y, int io, int B,
+                                                                     int Hs, int Ws, int C, int relu_out, int ntiles, long long plane,
+                                                                     long long wplane, int dbg) {
+  // dbg (DPTX_HX_DBG, timing ablations only -- results are wrong): 1 no MFMA phase, 2 no window build, 4 no weight DMA
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Wl = smem;                      // [2][9][32][128 B]
-  char* P = smem + 2 * HX_WPL;          // [2][10][34][128 B]
-  float* cst = (float*)(smem + 2 * HX_WPL + 2 * HX_PPL);
+  char* Wl = smem;                      // [2][9][32][64 B]
+  char* P = smem + 2 * HX_WPL;          // [2][10][34][64 B]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -281,43 +287,39 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
   const float ry = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
   const float rx = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
 
-  if (tid < 32) cst[tid] = b2[tid];
-  if (tid < 32 * C) cst[32 + tid] = w4[tid];
-  if (tid < C) cst[128 + tid] = b4[tid];
-
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;
   const int t_beg = blockIdx.x * per, t_end = min(t_beg + per, ntiles);
 
-  // window builder: an ITEM is (window column, 8-channel chunk of the half, row half): five window rows of one column from
-  // four source rows.  The 32 inner columns (1..32) give exactly 512 items -- one per thread; the two halo columns (0 and 33:
-  // 32 items) are built by the first 32 threads in a second pass.
-  const int wx_main = 1 + ((tid >> 3) & 31), wch = tid & 7, rh_main = tid >> 8;
+  // window builder: an ITEM is (window column 0..33, 8-channel chunk 0..3 of the quarter, row half): five window rows of one
+  // column from four source rows.  272 items: one per thread, the last 16 (column 33, row half 1: items 256..271) by the first
+  // 16 threads in a second pass.
+  auto item_of = [](int i, int& wx, int& wch, int& rh) { rh = i >= 136 ? 1 : 0; const int r = i - 136 * rh; wx = r >> 2; wch = r & 3; };
 
-  // weight DMA: wave-instruction q (0..71) moves the 1 KB piece [plane = q / 36][rows 8 (q % 36) .. + 7 of (tap, n)][8 chunks];
-  // lane l -> row r = 8 (q % 36) + l / 8 (tap = r / 32, n = r % 32), LDS chunk l % 8 holds SOURCE chunk (l % 8) ^ ((n >> 1) & 7)
+  // weight DMA: wave-instruction q (0..35) moves the 1 KB piece [plane = q / 18][rows 16 (q % 18) .. + 15 of (tap, n)][4 chunks];
+  // lane l -> row r = 16 (q % 18) + l / 4 (tap = r / 32, n = r % 32), LDS chunk l % 4 holds SOURCE chunk (l % 4) ^ ((n >> 2) & 3)
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(W2), 0, (int)((wplane + 32 * 1152) * 2), 0x00020000);
-  auto issue_w = [&](int half) {
+  auto issue_w = [&](int quarter) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int q = wave * 9 + k;
-      const int pl = q / 36, r = 8 * (q % 36) + (lane >> 3);
+      const int pl = q / 18, r = 16 * (q % 18) + (lane >> 2);
       const int tap = r >> 5, n = r & 31;
-      const int sch = (lane & 7) ^ ((n >> 1) & 7);
-      const unsigned off = (unsigned)(((long long)pl * wplane + n * 1152 + tap * 128 + half * 64 + sch * 8) * 2);
+      const int sch = (lane & 3) ^ ((n >> 2) & 3);
+      const unsigned off = (unsigned)(((long long)pl * wplane + n * 1152 + tap * 128 + quarter * 32 + sch * 8) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(Wl + q * 1024), 16, off, 0, 0, 0);
     }
   };
 
   typedef u32x4_t SrcVecs[4][2][2];  // [source row][x0 / x1][plane]
   const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-  auto fetch = [&](int t, int half, int wx, int rh, SrcVecs& S) {
+  auto fetch = [&](int t, int quarter, int wx, int wch, int rh, SrcVecs& S) {
     const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int ox = tx * 32 - 1 + wx;
     const bool vx = ox >= 0 && ox < Wo;
     const float sx = rx * (float)(vx ? ox : 0);
     const int x0 = (int)sx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
     const int ybase = (int)(ry * (float)max(ty * 8 - 1 + 5 * rh, 0));
-    const uint16_t* img = H0 + (long long)b * Hs * Ws * 128 + half * 64 + wch * 8;
+    const uint16_t* img = H0 + (long long)b * Hs * Ws * 128 + quarter * 32 + wch * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = min(ybase + j, Hs - 1);
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
     }
   };
   // five window rows (5 rh .. 5 rh + 4) of column wx into both planes of the window (zero outside the image: the conv's padding)
-  auto build = [&](int oy0, int ox0, int wx, int rh, const SrcVecs& S) {
+  auto build = [&](int oy0, int ox0, int wx, int wch, int rh, const SrcVecs& S) {
     const int ox = ox0 - 1 + wx;
     const bool vx = ox >= 0 && ox < Wo;
     const float sx = rx * (float)(vx ? ox : 0);
@@ -338,10 +340,7 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
     const int ybase = (int)(ry * (float)max(oy0 - 1 + 5 * rh, 0));
     float T[4][8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      hblend2<DT>(S[j][0], S[j][1], lx0, lx1, T[j]);
-      __builtin_amdgcn_sched_barrier(0);   // row by row (registers: interleaved, the five rows below alone take ~150)
-    }
+    for (int j = 0; j < 4; ++j) hblend2<DT>(S[j][0], S[j][1], lx0, lx1, T[j]);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       const int r = 5 * rh + k, oy = oy0 - 1 + r;
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
         const float sy = ry * (float)oy;
         const int y0 = (int)sy;
         const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
-        const int j0 = y0 - ybase;  // 0..2 (uniform over the threads of a row half); slot j0 + 1 holds row min(y0 + 1, Hs - 1) = ATen's y1
+        const int j0 = y0 - ybase;  // 0..2; slot j0 + 1 holds row min(y0 + 1, Hs - 1) = ATen's y1
         if (j0 == 0) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[1][e], __fmul_rn(ly0, T[0][e]));
@@ -372,10 +371,9 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
       for (int e = 0; e < 8; ++e) lf[e] = o[e] - hf[e];
       const uint4 lo = pack8<DT>(lf);
       const int idx = r * HT_PC + wx;
-      char* dst = P + idx * 128 + ((wch ^ ((idx >> 1) & 7)) << 4);
+      char* dst = P + idx * 64 + ((wch ^ ((idx >> 2) & 3)) << 4);
       *(u32x4_t*)dst = u32x4_t{hi.x, hi.y, hi.z, hi.w};
       *(u32x4_t*)(dst + HX_PPL) = u32x4_t{lo.x, lo.y, lo.z, lo.w};
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -384,86 +382,97 @@ __global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t
   for (int t = t_beg; t < t_end; ++t) {
     const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int oy0 = ty * 8, ox0 = tx * 32;
-    f32x16_t acc;
+    f32x16_t acc[2];   // output rows 2 wave, 2 wave + 1
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      // ---- phase A: this half's weights by DMA, its window from the source vectors
-      issue_w(half);
-      {
-        // (the source vectors are fetched here, not one half ahead: 64 more registers across the MFMA phase spill)
+    for (int quarter = 0; quarter < 4; ++quarter) {
+      // ---- phase A: this quarter's weights by DMA, its window from the source vectors (the CU's other block is in its MFMA
+      // phase meanwhile)
+      if (!(dbg & 4)) issue_w(quarter);
+      if (!(dbg & 2)) {
+        int wx, wch, rh;
+        item_of(tid, wx, wch, rh);
         SrcVecs S;
-        fetch(t, half, wx_main, rh_main, S);
-        build(oy0, ox0, wx_main, rh_main, S);
+        fetch(t, quarter, wx, wch, rh, S);
+        build(oy0, ox0, wx, wch, rh, S);
       }
-      if (tid < 32) {   // the two halo columns
-        SrcVecs H;
-        const int hx = (tid >> 3) & 1 ? HT_PC - 1 : 0, hrh = tid >> 4;
-        fetch(t, half, hx, hrh, H);
-        build(oy0, ox0, hx, hrh, H);
+      if (tid < 16 && !(dbg & 2)) {
+        int wx, wch, rh;
+        item_of(256 + tid, wx, wch, rh);
+        SrcVecs S;
+        fetch(t, quarter, wx, wch, rh, S);
+        build(oy0, ox0, wx, wch, rh, S);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight pieces of this wave have landed (the barrier publishes them)
       __syncthreads();
 
-      // ---- phase B: 36 k-steps x (hi*lo + lo*hi + hi*hi); transposed: acc[r] = channel (r&3)+8(r>>2)+4 lh of pixel lr
+      // ---- phase B: 18 k-steps x 2 rows x (hi*lo + lo*hi + hi*hi); transposed: acc[i][r] = channel (r&3)+8(r>>2)+4 lh of pixel
+      // lr of output row 2 wave + i
       {
-        u32x4_t wf[2][2], pf[2][2];  // [set][plane]
-        // (tap, cb): channels 16 cb .. 16 cb + 15 of the half at window pixel (wave + ky, lr + kx)
-        auto read_ks = [&](int tap, int cb, u32x4_t (&w)[2], u32x4_t (&q)[2]) {
+        u32x4_t wf[2][2], pf[2][2][2];  // [set][plane], [set][row][plane]
+        // (tap, cb): channels 16 cb .. 16 cb + 15 of the quarter at window pixels (2 wave + i + ky, lr + kx)
+        auto read_ks = [&](int tap, int cb, u32x4_t (&w)[2], u32x4_t (&q)[2][2]) {
           const int ky = tap / 3, kx = tap - ky * 3;
           const int chunk = 2 * cb + lh;
-          const char* wr = Wl + (tap * 32 + lr) * 128 + ((chunk ^ ((lr >> 1) & 7)) << 4);
-          const int idx = (wave + ky) * HT_PC + lr + kx;
-          const char* pr = P + idx * 128 + ((chunk ^ ((idx >> 1) & 7)) << 4);
+          const char* wr = Wl + (tap * 32 + lr) * 64 + ((chunk ^ ((lr >> 2) & 3)) << 4);
           w[0] = *(const u32x4_t*)wr;
           w[1] = *(const u32x4_t*)(wr + HX_WPL);
-          q[0] = *(const u32x4_t*)pr;
-          q[1] = *(const u32x4_t*)(pr + HX_PPL);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int idx = (2 * wave + i + ky) * HT_PC + lr + kx;
+            const char* pr = P + idx * 64 + ((chunk ^ ((idx >> 2) & 3)) << 4);
+            q[i][0] = *(const u32x4_t*)pr;
+            q[i][1] = *(const u32x4_t*)(pr + HX_PPL);
+          }
         };
-        // the tap loop stays a loop (fully unrolled, hipcc keeps the 36 + 36 swizzled fragment addresses live across the tile
-        // loop and spills); the reads still run one k-step ahead of the MFMAs, across the tap boundary as well
         read_ks(0, 0, wf[0], pf[0]);
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < ((dbg & 1) ? 0 : 9); ++tap) {
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb) {
-            if (cb < 3) read_ks(tap, cb + 1, wf[(cb + 1) & 1], pf[(cb + 1) & 1]);
+          for (int cb = 0; cb < 2; ++cb) {
+            if (cb < 1) read_ks(tap, cb + 1, wf[(cb + 1) & 1], pf[(cb + 1) & 1]);
             else if (tap + 1 < 9) read_ks(tap + 1, 0, wf[0], pf[0]);
             __builtin_amdgcn_sched_barrier(0);
-            acc = T16<DT>::mfma32(wf[cb & 1][0], pf[cb & 1][1], acc);   // w_hi * a_lo
-            acc = T16<DT>::mfma32(wf[cb & 1][1], pf[cb & 1][0], acc);   // w_lo * a_hi
-            acc = T16<DT>::mfma32(wf[cb & 1][0], pf[cb & 1][0], acc);   // w_hi * a_hi
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc[i] = T16<DT>::mfma32(wf[cb & 1][0], pf[cb & 1][i][1], acc[i]);   // w_hi * a_lo
+              acc[i] = T16<DT>::mfma32(wf[cb & 1][1], pf[cb & 1][i][0], acc[i]);   // w_lo * a_hi
+              acc[i] = T16<DT>::mfma32(wf[cb & 1][0], pf[cb & 1][i][0], acc[i]);   // w_hi * a_hi
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        if (half == 1) {
-          float h[16];
+        if (quarter == 3) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 bb = *(const float4*)(cst + 8 * q + 4 * lh);
-            h[4 * q + 0] = fmaxf(acc[4 * q + 0] + bb.x, 0.f);
-            h[4 * q + 1] = fmaxf(acc[4 * q + 1] + bb.y, 0.f);
-            h[4 * q + 2] = fmaxf(acc[4 * q + 2] + bb.z, 0.f);
-            h[4 * q + 3] = fmaxf(acc[4 * q + 3] + bb.w, 0.f);
-          }
-          const int oy = oy0 + wave;
-          for (int c = 0; c < C; ++c) {
-            float sacc = 0.f;
+          for (int i = 0; i < 2; ++i) {
+            float h[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float4 ww = *(const float4*)(cst + 32 + c * 32 + 8 * q + 4 * lh);
-              sacc += ww.x * h[4 * q + 0] + ww.y * h[4 * q + 1] + ww.z * h[4 * q + 2] + ww.w * h[4 * q + 3];
+              const float4 bb = *(const float4*)(b2 + 8 * q + 4 * lh);
+              h[4 * q + 0] = fmaxf(acc[i][4 * q + 0] + bb.x, 0.f);
+              h[4 * q + 1] = fmaxf(acc[i][4 * q + 1] + bb.y, 0.f);
+              h[4 * q + 2] = fmaxf(acc[i][4 * q + 2] + bb.z, 0.f);
+              h[4 * q + 3] = fmaxf(acc[i][4 * q + 3] + bb.w, 0.f);
             }
-            sacc += __shfl_xor(sacc, 32);
-            sacc += cst[128 + c];
-            if (relu_out) sacc = fmaxf(sacc, 0.f);
-            if ((c & 1) == lh) io_store(y, (((long long)b * C + c) * Ho + oy) * Wo + ox0 + lr, sacc, io);
+            const int oy = oy0 + 2 * wave + i;
+            for (int c = 0; c < C; ++c) {
+              float sacc = 0.f;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 ww = *(const float4*)(w4 + c * 32 + 8 * q + 4 * lh);
+                sacc += ww.x * h[4 * q + 0] + ww.y * h[4 * q + 1] + ww.z * h[4 * q + 2] + ww.w * h[4 * q + 3];
+              }
+              sacc += __shfl_xor(sacc, 32);
+              sacc += b4[c];
+              if (relu_out) sacc = fmaxf(sacc, 0.f);
+              if ((c & 1) == lh) io_store(y, (((long long)b * C + c) * Ho + oy) * Wo + ox0 + lr, sacc, io);
+            }
           }
         }
       }
-      __syncthreads();  // weights and window are rebuilt for the next half
+      __syncthreads();  // weights and window are rebuilt for the next quarter
     }
   }
 #endif
@@ -487,8 +496,11 @@ hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const floa
     if (mode != MODE_FP16X3 || pl.act == 0 || pl.w == 0 || (pl.w + 32 * 1152) * 2 >= (1ll << 31)) return hipErrorInvalidValue;
     auto k = head_tail_x3_kernel<DT_FP16>;
     ensure_dyn_smem((const void*)k, HX_SMEM);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(HX_THREADS), HX_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, io, B,
-                       Hs, Ws, C, relu_out, ntiles, pl.act, pl.w);
+    const int grid2 = ntiles < 2 * cus ? ntiles : 2 * cus;   // two blocks per CU
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("DPTX_HX_DBG"); dbg = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(k, dim3(grid2), dim3(HX_THREADS), HX_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, io, B,
+                       Hs, Ws, C, relu_out, ntiles, pl.act, pl.w, dbg);
     return hipGetLastError();
   }
   if (mode == MODE_BF16) {
