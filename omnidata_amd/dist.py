@@ -48,15 +48,23 @@ def broadcast_fp8_calibration(eng, x: Optional[torch.Tensor], device: torch.devi
 
 
 def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dtype: str, device_index: int, src: int = 0,
-                            dual: bool = False, x3_groups=0, backbone: str = "vitb_rn50_384"):
+                            dual: bool = False, x3_groups=0, backbone: str = "vitb_rn50_384", calib_x=None):
     """Every rank gets an Engine with identical packed weights; only `src` runs the host-side
-    fold/pack (state_dict_fn() is called on `src` only)."""
+    fold/pack (state_dict_fn() is called on `src` only).
+
+    dtype 'fp8': the activation scales of the e4m3 tensors are data, and replicas must agree on them -- `calib_x` (a
+    representative batch on `src`'s device; other ranks may pass None) is measured on `src` and the scales travel with
+    the weights (one more 512-byte broadcast).  Without `calib_x` the engine stays uncalibrated: calibrate one rank and
+    call broadcast_fp8_calibration, or every rank would calibrate on its own shard and the replicas would diverge
+    (the model warns when it has to calibrate implicitly)."""
     from .engine import Engine
     eng = Engine(num_channels=num_channels, max_batch=max_batch, dtype=dtype, device_id=device_index, dual=dual,
                  x3_groups=x3_groups, backbone=backbone)
     device = torch.device("cuda", device_index)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         eng.load_state_dict(state_dict_fn())
+        if dtype == "fp8" and calib_x is not None:
+            eng.calibrate_fp8(calib_x)
         return eng
     if dist.get_rank() == src:
         eng.load_state_dict(state_dict_fn())
@@ -66,4 +74,10 @@ def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dt
     else:
         blob = broadcast_blob(None, eng.packed_bytes, device, src)
         eng.import_packed(blob)
+    if dtype == "fp8":
+        # every rank takes part in the (collective) decision whether scales travel: src says whether it has a calibration batch
+        has = torch.tensor([1 if (dist.get_rank() == src and calib_x is not None) else 0], dtype=torch.int32, device=device)
+        dist.broadcast(has, src=src)
+        if int(has.item()):
+            broadcast_fp8_calibration(eng, calib_x if dist.get_rank() == src else None, device, src)
     return eng

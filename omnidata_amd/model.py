@@ -133,7 +133,8 @@ class DPTDepthModel(_EngineGuards, BaseModel):
     fp32 reference forward (profiles/r02_precision_frontier.md, oracle/precision_layers.py).  'fp16x3' / 'bf16x3' run
     everything with 3 MFMAs (reference-grade, ~1e-5 / ~1e-4).  'bf16' / 'fp16' are single-pass THROUGHPUT modes: ~2x
     faster, but ~6e-2 / ~9e-3 max-abs from the reference on the seeded weights -- NOT within 1e-3; 'fp8' additionally
-    runs the decoder convolutions on e4m3 operands.  ``max_batch`` -- arena size (larger batches are chunked).
+    runs decoder convolutions on e4m3 operands: by default the six that keep it within 2x the bf16 mode's error
+    (oracle/fp8_layers.py), with ``fp8_all=True`` all 19 eligible ones (faster, 7-9 degrees of mean angular error).  ``max_batch`` -- arena size (larger batches are chunked).
 
     ``overflow_fallback`` (default on): the fp16 range guard described in ``_EngineGuards`` -- an on-device scan per
     forward, read after the first forward of a set of weights and every 16th one afterwards; falls back to bf16 planes.
@@ -142,8 +143,9 @@ class DPTDepthModel(_EngineGuards, BaseModel):
     def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,
                  backbone: str = "vitb_rn50_384", features: int = 256, readout: str = "project",
                  channels_last: bool = False, use_bn: bool = False, dtype: str = "mixed",
-                 max_batch: int = 32, init_seed: int = 0, x3_groups=0, overflow_fallback: bool = True):
+                 max_batch: int = 32, init_seed: int = 0, x3_groups=0, overflow_fallback: bool = True, fp8_all: bool = False):
         super().__init__()
+        self.fp8_all = bool(fp8_all)   # dtype 'fp8': all 19 eligible decoder convs on e4m3 (lossy) instead of the six safe ones
         if backbone not in BACKBONES:
             # blocks.py:42-44: unknown backbones print and assert
             print(f"Backbone '{backbone}' not implemented")
@@ -197,7 +199,7 @@ class DPTDepthModel(_EngineGuards, BaseModel):
                 self._engine.close()
             eng = Engine(num_channels=self.num_channels, max_batch=self._chunk(), dtype=self.engine_dtype,
                          device_id=key[0], non_negative=self.non_negative, max_hw=self.max_hw,
-                         x3_groups=self.x3_groups, backbone=self.backbone)
+                         x3_groups=self.x3_groups, backbone=self.backbone, flags=16 if self.fp8_all else 0)
             eng.load_state_dict(super().state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine
@@ -252,9 +254,10 @@ class DPTDualTaskModel(_EngineGuards, nn.Module):
     """
 
     def __init__(self, dtype: str = "mixed", max_batch: int = 32, init_seed: int = 0, non_negative: bool = True,
-                 x3_groups=0, overflow_fallback: bool = True):
+                 x3_groups=0, overflow_fallback: bool = True, fp8_all: bool = False):
         super().__init__()
         self._init_guards(overflow_fallback)
+        self.fp8_all = bool(fp8_all)
         self.engine_dtype = dtype
         self.x3_groups = x3_groups
         self.max_batch = max(1, min(int(max_batch), 48))
@@ -305,7 +308,8 @@ class DPTDualTaskModel(_EngineGuards, nn.Module):
             if self._engine is not None:
                 self._engine.close()
             eng = Engine(num_channels=3, max_batch=self._chunk(), dtype=self.engine_dtype, device_id=key[0],
-                         non_negative=self.non_negative, max_hw=self.max_hw, dual=True, x3_groups=self.x3_groups)
+                         non_negative=self.non_negative, max_hw=self.max_hw, dual=True, x3_groups=self.x3_groups,
+                         flags=16 if self.fp8_all else 0)
             eng.load_state_dict(super().state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine

@@ -67,8 +67,9 @@ def test_fp8_conv(case):
 
 
 def test_fp8_end_to_end_stated_tolerance():
+    """The LOSSY preset (fp8_all: all 19 eligible decoder convolutions on e4m3) against the oracle, stage by stage."""
     sd, x, ref, otaps = oracle_case("normal", 3, 0, 1)
-    model = DPTDepthModel(num_channels=3, dtype="fp8", max_batch=1)
+    model = DPTDepthModel(num_channels=3, dtype="fp8", max_batch=1, fp8_all=True)
     model.load_state_dict(sd)
     model.to(DEV)
     eng = model._get_engine(torch.device(DEV))
@@ -76,7 +77,7 @@ def test_fp8_end_to_end_stated_tolerance():
     y = model(x.to(DEV)).cpu()
     d = (y - ref).abs()
     ang = mean_angular_error_deg(y.clamp(0, 1), ref.clamp(0, 1))
-    print(f"\n[fp8 decoder, bf16 elsewhere] max|d|={d.max():.3e} rms={d.pow(2).mean().sqrt():.3e} mean angular error {ang:.2f} deg")
+    print(f"\n[fp8_all decoder, bf16 elsewhere] max|d|={d.max():.3e} rms={d.pow(2).mean().sqrt():.3e} mean angular error {ang:.2f} deg")
     rel = {}
     for n in ["s2", "blk11", "l1_rn", "l4_rn", "p4", "p3", "p2", "p1", "h0"]:
         got, want = eng.tap(n), otaps[n]
@@ -89,10 +90,12 @@ def test_fp8_end_to_end_stated_tolerance():
 
 @pytest.mark.parametrize("family", ["default", "trained"])
 def test_fp8_error_on_both_weight_families(family):
-    """The stated tolerance on BOTH synthetic weight families (omnidata_amd.weights: 'default' = chaotic random residual net,
-    'trained' = trained-like conditioning), next to the bf16 mode's error on the same case: e4m3 operands carry 2^-4
-    relative rounding noise per element, so the fp8 decoder costs a multiple of the bf16 error -- it is a throughput mode
-    and is labelled as such wherever its img/s is quoted (README.md, bench.py `also`)."""
+    """BASELINE configs[4] 'fp8 MFMA weights', with a bar: the DEFAULT fp8 mode -- the six resConfUnit1
+    convolutions of refinenet1..3 on e4m3 operands, chosen layer by layer on the CPU oracle (oracle/fp8_layers.py) -- stays
+    within 2 x the bf16 engine's mean angular error on BOTH synthetic weight families (omnidata_amd.weights: 'default' =
+    chaotic random residual net, 'trained' = trained-like conditioning).  The fp8 MFMA takes e4m3 on both operands, so
+    'fp8 weights' means e4m3 activations as well, 2^-4 relative rounding per element: with all 19 eligible convolutions
+    (fp8_all, round 3's mode) the error is 2 - 7 x the bf16 one -- a lossy throughput mode with the loose bar it had."""
     from omnidata_amd.weights import random_state_dict
     from oracle.dpt_oracle import dpt_forward
     sd = random_state_dict(0, 3, family=family)
@@ -100,14 +103,17 @@ def test_fp8_error_on_both_weight_families(family):
     oracle_threads()
     ref = dpt_forward(sd, x)
     res = {}
-    for dtype in ("bf16", "fp8"):
-        m = DPTDepthModel(num_channels=3, dtype=dtype, max_batch=1)
+    for name, kw in (("bf16", dict(dtype="bf16")), ("fp8", dict(dtype="fp8")), ("fp8_all", dict(dtype="fp8", fp8_all=True))):
+        m = DPTDepthModel(num_channels=3, max_batch=1, **kw)
         m.load_state_dict(sd)
         m.to(DEV)
+        m.calibrate(x.to(DEV)) if kw["dtype"] == "fp8" else None
         y = m(x.to(DEV)).cpu()
-        res[dtype] = ((y - ref).pow(2).mean().sqrt().item(), mean_angular_error_deg(y.clamp(0, 1), ref.clamp(0, 1)))
-    print(f"\n[{family}] bf16 rms {res['bf16'][0]:.3e} / {res['bf16'][1]:.2f} deg;  fp8 decoder rms {res['fp8'][0]:.3e} / {res['fp8'][1]:.2f} deg")
-    assert res["fp8"][1] < 20.0 and res["fp8"][0] < 6e-2
+        res[name] = ((y - ref).pow(2).mean().sqrt().item(), mean_angular_error_deg(y.clamp(0, 1), ref.clamp(0, 1)))
+    print(f"\n[{family}] bf16 rms {res['bf16'][0]:.3e} / {res['bf16'][1]:.2f} deg;  fp8 (6 safe convs) rms {res['fp8'][0]:.3e} / "
+          f"{res['fp8'][1]:.2f} deg;  fp8_all (19 convs) rms {res['fp8_all'][0]:.3e} / {res['fp8_all'][1]:.2f} deg")
+    assert res["fp8"][1] <= 2.0 * res["bf16"][1], "the default fp8 mode must stay within 2 x the bf16 mode's angular error"
+    assert res["fp8_all"][1] < 20.0 and res["fp8_all"][0] < 6e-2
 
 
 def test_fp8_activation_scales_follow_the_data():
@@ -127,7 +133,7 @@ def test_fp8_activation_scales_follow_the_data():
     big["scratch.output_conv.0.weight"] /= 600.0
     outs = {}
     for name, w in (("orig", sd), ("x600", big)):
-        m = DPTDepthModel(num_channels=3, dtype="fp8", max_batch=1)
+        m = DPTDepthModel(num_channels=3, dtype="fp8", max_batch=1, fp8_all=True)
         m.load_state_dict(w)
         m.to(DEV)
         outs[name] = m(x.to(DEV)).cpu()
@@ -143,7 +149,7 @@ def test_fp8_activation_scales_follow_the_data():
 def test_fp8_dual_task_runs_and_is_deterministic():
     sd = random_dual_state_dict(3)
     x = synthetic_input(11, 3, "normal")
-    dual = DPTDualTaskModel(dtype="fp8", max_batch=3)
+    dual = DPTDualTaskModel(dtype="fp8", max_batch=3, fp8_all=True)
     dual.load_state_dict(sd)
     dual.to(DEV)
     yn, yd = dual(x.to(DEV))

@@ -19,6 +19,7 @@ CASES = [  # dtype, dual, B, streams
     ("mixed", False, 3, 2), ("mixed", True, 3, 2), ("mixed", False, 1, 1),
     ("fp16x3", False, 2, 2), ("bf16x3", False, 2, 1),
     ("fp8", False, 3, 2), ("fp8", True, 3, 2), ("fp8", True, 3, 1), ("fp8", False, 1, 1),
+    ("fp8all", True, 3, 2), ("fp8all", False, 3, 2),   # DPTX_FLAG_FP8_ALL: all 19 eligible decoder convolutions on e4m3
 ]
 
 
@@ -34,7 +35,9 @@ def _fwd(eng, x, dual):
 
 @pytest.mark.parametrize("dtype,dual,B,streams", CASES)
 def test_forward_does_not_depend_on_prior_arena_contents(dtype, dual, B, streams):
-    eng = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, dual=dual, streams=streams)
+    flags = 16 if dtype == "fp8all" else 0
+    dtype = "fp8" if dtype == "fp8all" else dtype
+    eng = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, dual=dual, streams=streams, flags=flags)
     eng.load_state_dict(random_dual_state_dict(3) if dual else random_state_dict(3, 3))
     x = synthetic_input(11, B, "normal").to(DEV)
     if dtype == "fp8":

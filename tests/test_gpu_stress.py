@@ -13,13 +13,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _stress(dtype, dual, B, streams, iters):
+def _stress(dtype, dual, B, streams, iters, flags=0):
     from omnidata_amd.weights import random_dual_state_dict
     sd = random_dual_state_dict(0) if dual else random_state_dict(0, 3)
     x = synthetic_input(5, B, "normal").to(DEV)
 
     def make(ns):
-        e = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, dual=dual, streams=ns)
+        e = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, dual=dual, streams=ns, flags=flags)
         e.load_state_dict(sd)
         return e
 
@@ -66,11 +66,12 @@ def test_multi_stream_schedule_stress_bit_identical(dtype, streams, iters):
     _stress(dtype, False, 6, streams, iters)
 
 
-@pytest.mark.parametrize("dual,B,iters", [(False, 32, 150), (True, 32, 100), (True, 3, 600), (False, 3, 600)])
-def test_fp8_stress_bit_identical(dual, B, iters):
+@pytest.mark.parametrize("dual,B,iters,flags", [(False, 32, 150, 16), (True, 32, 100, 0), (True, 3, 600, 16), (False, 3, 600, 0)])
+def test_fp8_stress_bit_identical(dual, B, iters, flags):
     """VERDICT r3 (item 1c): the fp8 decoder under the two-stream schedule, single- and dual-task, at the benchmarked batch
-    and at the batch of the round-3 driver failure (B = 3: sub-batches of 2 + 1), against the single-stream result."""
-    _stress("fp8", dual, B, 2, iters)
+    and at the batch of the round-3 driver failure (B = 3: sub-batches of 2 + 1), against the single-stream result; both
+    presets (flags 16 = DPTX_FLAG_FP8_ALL: all 19 eligible convolutions on e4m3, the configuration that failed in round 3)."""
+    _stress("fp8", dual, B, 2, iters, flags)
 
 
 @pytest.mark.parametrize("dtype,B,iters", [("bf16", 32, 200), ("mixed", 32, 100), ("bf16", 2, 1500)])
