@@ -243,20 +243,22 @@ __global__ __launch_bounds__(HT_THREADS) void head_tail_kernel(const uint16_t* _
 //                                                      swizzle on the SOURCE chunk -- conflict-free ds_read_b128 of 64-byte rows)
 //   P  [plane][10 rows][34 cols][32 ch]   = 43 520 B  (a thread builds five window rows of one column and eight channels from
 //                                                      4 x 2 x 2 source vectors)
-// = 78.5 KB, 256 threads: two blocks fit a CU.  A wave owns two output rows (the weight fragments are read once for both): 18
-// k-steps x 2 rows x 3 MFMAs per quarter.  Measured at B = 32 (tools/gpu/r4_headx3_bench.py, DPTX_HX_DBG ablations): 1.53 ms per
-// launch = window build 0.57 + MFMA phase 0.77 (0.47 at the MFMA peak) + weight DMA 0.04 + skeleton / stores 0.18 -- the phases
-// of the two blocks do NOT overlap (the same 1.5-1.7 ms as the first form of this kernel, one 161 KB block of 512 threads per
-// CU with channel halves; starting the second block half a period late changes nothing): what is left is a warp-specialised
-// form in which builder waves run ahead of MFMA waves through a double-buffered window.  The weights are re-streamed per tile (147 KB per 8 x 32 pixels,
-// ~21 MB per CU and forward out of L2).  The 32-channel map stays in fp32 registers: bias + ReLU + the 1x1 projection + ReLU
-// as in the single-plane kernel; the unfused path rounds it to a hi/lo pair first (bound: tests/test_gpu_mixed.py).  The
-// up-sampled window is bit-identical to upsample2x_kernel<DT, 2> (same blend, same split).
-constexpr int HX_THREADS = 256;
+// = 78.5 KB per stage, TWO stages (157 KB): the block is warp-specialised -- waves 0..4 build the window and wave 5 streams
+// the weights of step g + 1 while waves 6..9 (the multipliers, two output rows each: the weight fragments are read once for
+// both) run the 18 k-steps x 2 rows x 3 MFMAs of step g; one s_barrier per step.  The first forms of this kernel ran the
+// two phases one after the other in all waves (one 161 KB block with channel halves, then two 78.5 KB blocks per CU): 1.53 -
+// 1.67 ms per launch at B = 32 -- the phases of co-resident blocks did not overlap by themselves.  This form: 1.43 ms;
+// with the MFMA phase removed 0.95 ms, with the window build removed 0.94 ms, without the weight DMA 1.38 ms
+// (tools/gpu/r4_headx3_bench.py, DPTX_HX_DBG).  Both halves sit at twice their own floor: the multipliers read one 1 KB
+// fragment from LDS per MFMA (w_hi, w_lo, and hi / lo of two rows for six MFMAs), which is the LDS port's rate, and the
+// builders' ds_write_b128 share that port -- a deeper register blocking (four rows per wave) needs a 16-row window that does
+// not fit two stages.  The weights are re-streamed per tile (147 KB per 8 x 32 pixels, ~21 MB per CU and forward out of L2).
+constexpr int HX_THREADS = 640;                 // waves 0..4 build the window, wave 5 streams the weights, waves 6..9 multiply
 constexpr int HX_WPL = 9 * 32 * 64;             // bytes of one weight plane of one channel quarter: [tap][n][4 chunks x 16 B]
 constexpr int HX_PPL = HT_PR * HT_PC * 64;      // bytes of one window plane of one channel quarter
-constexpr size_t HX_SMEM = 2 * HX_WPL + 2 * HX_PPL;   // 80 384 B: two blocks and 3 KB to spare (the head constants stay in memory)
-static_assert(2 * ((HX_SMEM + 1023) / 1024 * 1024) <= 160 * 1024, "two blocks per CU");
+constexpr int HX_STAGE = 2 * HX_WPL + 2 * HX_PPL;   // 80 384 B: [W hi | W lo | P hi | P lo]
+constexpr size_t HX_SMEM = 2 * HX_STAGE;        // two stages: 160 768 B (the head constants stay in memory)
+static_assert(HX_SMEM <= 160 * 1024, "one block per CU");
 
 template <int DT>
 __device__ __forceinline__ void hblend2(const u32x4_t (&s0)[2], const u32x4_t (&s1)[2], float lx0, float lx1, float (&t)[8]) {
@@ -268,16 +270,14 @@ __device__ __forceinline__ void hblend2(const u32x4_t (&s0)[2], const u32x4_t (&
 }
 
 template <int DT>
-__global__ __launch_bounds__(HX_THREADS, 2) void head_tail_x3_kernel(const uint16_t* __restrict__ H0, const uint16_t* __restrict__ W2,
-                                                                     const float* __restrict__ b2, const float* __restrict__ w4,
-                                                                     const float* __restrict__ b4, void* __restrict__ y, int io, int B,
-                                                                     int Hs, int Ws, int C, int relu_out, int ntiles, long long plane,
-                                                                     long long wplane, int dbg) {
+__global__ __launch_bounds__(HX_THREADS) void head_tail_x3_kernel(const uint16_t* __restrict__ H0, const uint16_t* __restrict__ W2,
+                                                                  const float* __restrict__ b2, const float* __restrict__ w4,
+                                                                  const float* __restrict__ b4, void* __restrict__ y, int io, int B,
+                                                                  int Hs, int Ws, int C, int relu_out, int ntiles, long long plane,
+                                                                  long long wplane, int dbg) {
   // dbg (DPTX_HX_DBG, timing ablations only -- results are wrong): 1 no MFMA phase, 2 no window build, 4 no weight DMA
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Wl = smem;                      // [2][9][32][64 B]
-  char* P = smem + 2 * HX_WPL;          // [2][10][34][64 B]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,190 +289,199 @@ __global__ __launch_bounds__(HX_THREADS, 2) void head_tail_x3_kernel(const uint1
 
   const int per = (ntiles + gridDim.x - 1) / gridDim.x;
   const int t_beg = blockIdx.x * per, t_end = min(t_beg + per, ntiles);
+  const int G = (t_end - t_beg) * 4;   // steps of this block: (tile, channel quarter); step g lives in LDS stage g & 1
+  if (G <= 0) return;
 
-  // window builder: an ITEM is (window column 0..33, 8-channel chunk 0..3 of the quarter, row half): five window rows of one
-  // column from four source rows.  272 items: one per thread, the last 16 (column 33, row half 1: items 256..271) by the first
-  // 16 threads in a second pass.
-  auto item_of = [](int i, int& wx, int& wch, int& rh) { rh = i >= 136 ? 1 : 0; const int r = i - 136 * rh; wx = r >> 2; wch = r & 3; };
-
-  // weight DMA: wave-instruction q (0..35) moves the 1 KB piece [plane = q / 18][rows 16 (q % 18) .. + 15 of (tap, n)][4 chunks];
-  // lane l -> row r = 16 (q % 18) + l / 4 (tap = r / 32, n = r % 32), LDS chunk l % 4 holds SOURCE chunk (l % 4) ^ ((n >> 2) & 3)
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(W2), 0, (int)((wplane + 32 * 1152) * 2), 0x00020000);
-  auto issue_w = [&](int quarter) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int q = wave * 9 + k;
-      const int pl = q / 18, r = 16 * (q % 18) + (lane >> 2);
-      const int tap = r >> 5, n = r & 31;
-      const int sch = (lane & 3) ^ ((n >> 2) & 3);
-      const unsigned off = (unsigned)(((long long)pl * wplane + n * 1152 + tap * 128 + quarter * 32 + sch * 8) * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(Wl + q * 1024), 16, off, 0, 0, 0);
-    }
-  };
-
-  typedef u32x4_t SrcVecs[4][2][2];  // [source row][x0 / x1][plane]
-  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-  auto fetch = [&](int t, int quarter, int wx, int wch, int rh, SrcVecs& S) {
-    const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int ox = tx * 32 - 1 + wx;
-    const bool vx = ox >= 0 && ox < Wo;
-    const float sx = rx * (float)(vx ? ox : 0);
-    const int x0 = (int)sx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-    const int ybase = (int)(ry * (float)max(ty * 8 - 1 + 5 * rh, 0));
-    const uint16_t* img = H0 + (long long)b * Hs * Ws * 128 + quarter * 32 + wch * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = min(ybase + j, Hs - 1);
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        S[j][0][pl] = vx ? *(const u32x4_t*)(img + pl * plane + ((long long)row * Ws + x0) * 128) : zero4;
-        S[j][1][pl] = vx ? *(const u32x4_t*)(img + pl * plane + ((long long)row * Ws + x1) * 128) : zero4;
-      }
-    }
-  };
-  // five window rows (5 rh .. 5 rh + 4) of column wx into both planes of the window (zero outside the image: the conv's padding)
-  auto build = [&](int oy0, int ox0, int wx, int wch, int rh, const SrcVecs& S) {
-    const int ox = ox0 - 1 + wx;
-    const bool vx = ox >= 0 && ox < Wo;
-    const float sx = rx * (float)(vx ? ox : 0);
-    const int x0 = (int)sx;
-    const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
-    const int ybase = (int)(ry * (float)max(oy0 - 1 + 5 * rh, 0));
-    float T[4][8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) hblend2<DT>(S[j][0], S[j][1], lx0, lx1, T[j]);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int r = 5 * rh + k, oy = oy0 - 1 + r;
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = 0.f;
-      if (vx && oy >= 0 && oy < Ho) {
-        const float sy = ry * (float)oy;
-        const int y0 = (int)sy;
-        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
-        const int j0 = y0 - ybase;  // 0..2; slot j0 + 1 holds row min(y0 + 1, Hs - 1) = ATen's y1
-        if (j0 == 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[1][e], __fmul_rn(ly0, T[0][e]));
-        } else if (j0 == 1) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[2][e], __fmul_rn(ly0, T[1][e]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[3][e], __fmul_rn(ly0, T[2][e]));
-        }
-      }
-      // hi / lo split exactly as store8f<DT, 2>
-      const uint4 hi = pack8<DT>(o);
-      float hf[8], lf[8];
-      unpack8<DT>(hi, hf);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) lf[e] = o[e] - hf[e];
-      const uint4 lo = pack8<DT>(lf);
-      const int idx = r * HT_PC + wx;
-      char* dst = P + idx * 64 + ((wch ^ ((idx >> 2) & 3)) << 4);
-      *(u32x4_t*)dst = u32x4_t{hi.x, hi.y, hi.z, hi.w};
-      *(u32x4_t*)(dst + HX_PPL) = u32x4_t{lo.x, lo.y, lo.z, lo.w};
-    }
-  };
-
-  __syncthreads();
-
-  for (int t = t_beg; t < t_end; ++t) {
-    const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int oy0 = ty * 8, ox0 = tx * 32;
-    f32x16_t acc[2];   // output rows 2 wave, 2 wave + 1
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-
+  // Schedule (one s_barrier per step, G of them on either side):
+  //   builders:    for g: build(g) into stage g & 1;  barrier B_g
+  //   multipliers: barrier B_0;  for g: consume(g) out of stage g & 1;  barrier B_(g+1) unless g is the last step
+  // Before B_g the builders write stage g & 1 while the multipliers read stage (g - 1) & 1; behind B_g the builders move on to
+  // stage (g + 1) & 1 = the one the multipliers have just finished with.
+  if (wave == 5) {
+    // ============================================================ weight wave: 36 LDS-DMA pieces per step
+    // piece q (0..35) = [plane = q / 18][rows 16 (q % 18) .. + 15 of (tap, n)][4 chunks]; lane l -> row r = 16 (q % 18) + l / 4
+    // (tap = r / 32, n = r % 32), LDS chunk l % 4 holds SOURCE chunk (l % 4) ^ ((n >> 2) & 3)
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(W2), 0, (int)((wplane + 32 * 1152) * 2), 0x00020000);
 #pragma unroll 1
-    for (int quarter = 0; quarter < 4; ++quarter) {
-      // ---- phase A: this quarter's weights by DMA, its window from the source vectors (the CU's other block is in its MFMA
-      // phase meanwhile)
-      if (!(dbg & 4)) issue_w(quarter);
-      if (!(dbg & 2)) {
-        int wx, wch, rh;
-        item_of(tid, wx, wch, rh);
-        SrcVecs S;
-        fetch(t, quarter, wx, wch, rh, S);
-        build(oy0, ox0, wx, wch, rh, S);
+    for (int g = 0; g < G; ++g) {
+      const int quarter = g & 3;
+      char* Wl = smem + (g & 1) * HX_STAGE;
+      if (!(dbg & 4)) {
+#pragma unroll 6
+        for (int q = 0; q < 36; ++q) {
+          const int pl = q / 18, r = 16 * (q % 18) + (lane >> 2);
+          const int tap = r >> 5, n = r & 31;
+          const int sch = (lane & 3) ^ ((n >> 2) & 3);
+          const unsigned off = (unsigned)(((long long)pl * wplane + n * 1152 + tap * 128 + quarter * 32 + sch * 8) * 2);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(Wl + q * 1024), 16, off, 0, 0, 0);
+        }
       }
-      if (tid < 16 && !(dbg & 2)) {
-        int wx, wch, rh;
-        item_of(256 + tid, wx, wch, rh);
-        SrcVecs S;
-        fetch(t, quarter, wx, wch, rh, S);
-        build(oy0, ox0, wx, wch, rh, S);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight pieces of this wave have landed (the barrier publishes them)
-      __syncthreads();
-
-      // ---- phase B: 18 k-steps x 2 rows x (hi*lo + lo*hi + hi*hi); transposed: acc[i][r] = channel (r&3)+8(r>>2)+4 lh of pixel
-      // lr of output row 2 wave + i
-      {
-        u32x4_t wf[2][2], pf[2][2][2];  // [set][plane], [set][row][plane]
-        // (tap, cb): channels 16 cb .. 16 cb + 15 of the quarter at window pixels (2 wave + i + ky, lr + kx)
-        auto read_ks = [&](int tap, int cb, u32x4_t (&w)[2], u32x4_t (&q)[2][2]) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-          const int chunk = 2 * cb + lh;
-          const char* wr = Wl + (tap * 32 + lr) * 64 + ((chunk ^ ((lr >> 2) & 3)) << 4);
-          w[0] = *(const u32x4_t*)wr;
-          w[1] = *(const u32x4_t*)(wr + HX_WPL);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int idx = (2 * wave + i + ky) * HT_PC + lr + kx;
-            const char* pr = P + idx * 64 + ((chunk ^ ((idx >> 2) & 3)) << 4);
-            q[i][0] = *(const u32x4_t*)pr;
-            q[i][1] = *(const u32x4_t*)(pr + HX_PPL);
-          }
-        };
-        read_ks(0, 0, wf[0], pf[0]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");   // B_g
+    }
+    return;
+  }
+  if (wave < 5) {
+    // ============================================================ window builders (320 threads, 272 items)
+    // an ITEM is (window column 0..33, 8-channel chunk 0..3 of the quarter, row half): five window rows of one column from four
+    // source rows
+    const int item = tid;
+    const int rh = item >= 136 ? 1 : 0, irem = item - 136 * rh, wx = irem >> 2, wch = irem & 3;
+    typedef u32x4_t SrcVecs[4][2][2];  // [source row][x0 / x1][plane]
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll 1
-        for (int tap = 0; tap < ((dbg & 1) ? 0 : 9); ++tap) {
+    for (int g = 0; g < G; ++g) {
+      const int t = t_beg + (g >> 2), quarter = g & 3;
+      char* P = smem + (g & 1) * HX_STAGE + 2 * HX_WPL;
+      const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+      const int oy0 = ty * 8, ox0 = tx * 32;
+      if (item < 2 * 136 && !(dbg & 2)) {
+        const int ox = ox0 - 1 + wx;
+        const bool vx = ox >= 0 && ox < Wo;
+        const float sx = rx * (float)(vx ? ox : 0);
+        const int x0 = (int)sx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+        const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+        const int ybase = (int)(ry * (float)max(oy0 - 1 + 5 * rh, 0));
+        const uint16_t* img = H0 + (long long)b * Hs * Ws * 128 + quarter * 32 + wch * 8;
+        SrcVecs S;
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            if (cb < 1) read_ks(tap, cb + 1, wf[(cb + 1) & 1], pf[(cb + 1) & 1]);
-            else if (tap + 1 < 9) read_ks(tap + 1, 0, wf[0], pf[0]);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 4; ++j) {
+          const int row = min(ybase + j, Hs - 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              acc[i] = T16<DT>::mfma32(wf[cb & 1][0], pf[cb & 1][i][1], acc[i]);   // w_hi * a_lo
-              acc[i] = T16<DT>::mfma32(wf[cb & 1][1], pf[cb & 1][i][0], acc[i]);   // w_lo * a_hi
-              acc[i] = T16<DT>::mfma32(wf[cb & 1][0], pf[cb & 1][i][0], acc[i]);   // w_hi * a_hi
-            }
-            __builtin_amdgcn_sched_barrier(0);
+          for (int pl = 0; pl < 2; ++pl) {
+            S[j][0][pl] = vx ? *(const u32x4_t*)(img + pl * plane + ((long long)row * Ws + x0) * 128) : zero4;
+            S[j][1][pl] = vx ? *(const u32x4_t*)(img + pl * plane + ((long long)row * Ws + x1) * 128) : zero4;
           }
         }
-        if (quarter == 3) {
+        float T[4][8];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            float h[16];
+        for (int j = 0; j < 4; ++j) hblend2<DT>(S[j][0], S[j][1], lx0, lx1, T[j]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 bb = *(const float4*)(b2 + 8 * q + 4 * lh);
-              h[4 * q + 0] = fmaxf(acc[i][4 * q + 0] + bb.x, 0.f);
-              h[4 * q + 1] = fmaxf(acc[i][4 * q + 1] + bb.y, 0.f);
-              h[4 * q + 2] = fmaxf(acc[i][4 * q + 2] + bb.z, 0.f);
-              h[4 * q + 3] = fmaxf(acc[i][4 * q + 3] + bb.w, 0.f);
-            }
-            const int oy = oy0 + 2 * wave + i;
-            for (int c = 0; c < C; ++c) {
-              float sacc = 0.f;
+        for (int k = 0; k < 5; ++k) {
+          const int r = 5 * rh + k, oy = oy0 - 1 + r;
+          float o[8];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float4 ww = *(const float4*)(w4 + c * 32 + 8 * q + 4 * lh);
-                sacc += ww.x * h[4 * q + 0] + ww.y * h[4 * q + 1] + ww.z * h[4 * q + 2] + ww.w * h[4 * q + 3];
-              }
-              sacc += __shfl_xor(sacc, 32);
-              sacc += b4[c];
-              if (relu_out) sacc = fmaxf(sacc, 0.f);
-              if ((c & 1) == lh) io_store(y, (((long long)b * C + c) * Ho + oy) * Wo + ox0 + lr, sacc, io);
+          for (int e = 0; e < 8; ++e) o[e] = 0.f;
+          if (vx && oy >= 0 && oy < Ho) {
+            const float sy = ry * (float)oy;
+            const int y0 = (int)sy;
+            const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+            const int j0 = y0 - ybase;  // 0..2; slot j0 + 1 holds row min(y0 + 1, Hs - 1) = ATen's y1
+            if (j0 == 0) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[1][e], __fmul_rn(ly0, T[0][e]));
+            } else if (j0 == 1) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[2][e], __fmul_rn(ly0, T[1][e]));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = __fmaf_rn(ly1, T[3][e], __fmul_rn(ly0, T[2][e]));
             }
           }
+          // hi / lo split exactly as store8f<DT, 2> (zero outside the image: the conv's padding)
+          const uint4 hi = pack8<DT>(o);
+          float hf[8], lf[8];
+          unpack8<DT>(hi, hf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) lf[e] = o[e] - hf[e];
+          const uint4 lo = pack8<DT>(lf);
+          const int idx = r * HT_PC + wx;
+          char* dst = P + idx * 64 + ((wch ^ ((idx >> 2) & 3)) << 4);
+          *(u32x4_t*)dst = u32x4_t{hi.x, hi.y, hi.z, hi.w};
+          *(u32x4_t*)(dst + HX_PPL) = u32x4_t{lo.x, lo.y, lo.z, lo.w};
         }
       }
-      __syncthreads();  // weights and window are rebuilt for the next quarter
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's window stores have landed
+      asm volatile("s_barrier" ::: "memory");                        // B_g
+    }
+    return;
+  }
+
+  // ============================================================== multipliers (waves 6..9): output rows 2 mw, 2 mw + 1
+  const int mw = wave - 6;
+  // fragment addresses inside a stage (bytes): chunk = 2 cb + lh sits at position chunk ^ key, so cb = 1 is the cb = 0 address
+  // with bit 5 flipped.  W: row (tap, n = lr) -> the tap is an immediate; P: one base per (tap, output row)
+  const int w_a0 = lr * 64 + ((lh ^ ((lr >> 2) & 3)) << 4);
+  int p_a0[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = (2 * mw + i + tap / 3) * HT_PC + lr + tap % 3;
+      p_a0[tap][i] = 2 * HX_WPL + idx * 64 + ((lh ^ ((idx >> 2) & 3)) << 4);
+    }
+  f32x16_t acc[2];
+  asm volatile("s_barrier" ::: "memory");   // B_0
+#pragma unroll 1
+  for (int g = 0; g < G; ++g) {
+    const int t = t_beg + (g >> 2), quarter = g & 3;
+    const char* St = smem + (g & 1) * HX_STAGE;
+    if (quarter == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    }
+    // 18 k-steps x 2 rows x (hi*lo + lo*hi + hi*hi); transposed: acc[i][r] = channel (r&3)+8(r>>2)+4 lh of pixel lr of row 2 mw + i
+    u32x4_t wf[2][2], pf[2][2][2];  // [set][plane], [set][row][plane]: the reads run one k-step ahead of the MFMAs (two ahead
+                                    // and s_setprio on these waves measured the same: profiles/r04_experiments.md)
+    auto read_ks = [&](int tap, int cb, u32x4_t (&w)[2], u32x4_t (&q)[2][2]) {   // tap, cb: compile-time after unrolling
+      const char* wr = St + ((w_a0 ^ (cb << 5)) + tap * 2048);
+      w[0] = *(const u32x4_t*)wr;
+      w[1] = *(const u32x4_t*)(wr + HX_WPL);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* pr = St + (p_a0[tap][i] ^ (cb << 5));
+        q[i][0] = *(const u32x4_t*)pr;
+        q[i][1] = *(const u32x4_t*)(pr + HX_PPL);
+      }
+    };
+    if (!(dbg & 1)) {
+      read_ks(0, 0, wf[0], pf[0]);
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) {
+        if (ks + 1 < 18) read_ks((ks + 1) >> 1, (ks + 1) & 1, wf[(ks + 1) & 1], pf[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // (the two rows alternate: consecutive MFMAs never share an accumulator)
+        acc[0] = T16<DT>::mfma32(wf[ks & 1][0], pf[ks & 1][0][1], acc[0]);   // w_hi * a_lo
+        acc[1] = T16<DT>::mfma32(wf[ks & 1][0], pf[ks & 1][1][1], acc[1]);
+        acc[0] = T16<DT>::mfma32(wf[ks & 1][1], pf[ks & 1][0][0], acc[0]);   // w_lo * a_hi
+        acc[1] = T16<DT>::mfma32(wf[ks & 1][1], pf[ks & 1][1][0], acc[1]);
+        acc[0] = T16<DT>::mfma32(wf[ks & 1][0], pf[ks & 1][0][0], acc[0]);   // w_hi * a_hi
+        acc[1] = T16<DT>::mfma32(wf[ks & 1][0], pf[ks & 1][1][0], acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (quarter == 3) {
+      const int b = t / tpi, rem = t - b * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+      const int oy0 = ty * 8, ox0 = tx * 32;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float h[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bb = *(const float4*)(b2 + 8 * q + 4 * lh);
+          h[4 * q + 0] = fmaxf(acc[i][4 * q + 0] + bb.x, 0.f);
+          h[4 * q + 1] = fmaxf(acc[i][4 * q + 1] + bb.y, 0.f);
+          h[4 * q + 2] = fmaxf(acc[i][4 * q + 2] + bb.z, 0.f);
+          h[4 * q + 3] = fmaxf(acc[i][4 * q + 3] + bb.w, 0.f);
+        }
+        const int oy = oy0 + 2 * mw + i;
+        for (int c = 0; c < C; ++c) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 ww = *(const float4*)(w4 + c * 32 + 8 * q + 4 * lh);
+            sacc += ww.x * h[4 * q + 0] + ww.y * h[4 * q + 1] + ww.z * h[4 * q + 2] + ww.w * h[4 * q + 3];
+          }
+          sacc += __shfl_xor(sacc, 32);
+          sacc += b4[c];
+          if (relu_out) sacc = fmaxf(sacc, 0.f);
+          if ((c & 1) == lh) io_store(y, (((long long)b * C + c) * Ho + oy) * Wo + ox0 + lr, sacc, io);
+        }
+      }
+    }
+    if (g + 1 < G) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of stage g & 1 are done
+      asm volatile("s_barrier" ::: "memory");               // B_(g+1)
     }
   }
 #endif
@@ -496,7 +505,7 @@ hipError_t launch_head_tail(int mode, const void* H0, const void* W2, const floa
     if (mode != MODE_FP16X3 || pl.act == 0 || pl.w == 0 || (pl.w + 32 * 1152) * 2 >= (1ll << 31)) return hipErrorInvalidValue;
     auto k = head_tail_x3_kernel<DT_FP16>;
     ensure_dyn_smem((const void*)k, HX_SMEM);
-    const int grid2 = ntiles < 2 * cus ? ntiles : 2 * cus;   // two blocks per CU
+    const int grid2 = grid;   // one block per CU
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("DPTX_HX_DBG"); dbg = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(k, dim3(grid2), dim3(HX_THREADS), HX_SMEM, stream, (const uint16_t*)H0, (const uint16_t*)W2, b2, w4, b4, y, io, B,
