@@ -183,11 +183,14 @@ int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y
                       int32_t batch, int32_t height, int32_t width, void* stream);
 
 /* dtype MIXED: per-layer precision inside the decoder (scratch.layerN_rn, refinenet*, output_conv.0 / .2).  `mfmas` = 1: the
- * convolution multiplies the hi planes only (one MFMA per product); 3: hi/lo planes, three MFMAs.  Layers that were never set
- * follow their group's bit in dptx_config.x3_groups.  Tensors between layers carry a lo plane exactly where a 3-MFMA consumer
- * reads it, so every assignment is valid.  With x3_groups = 0 dptx_create installs the default table (oracle/
- * precision_layers.py); DPTX_FLAG_GROUP_POLICY suppresses it.  May be called at any time before a forward; does not touch
- * the packed weights.  The reference has no counterpart (it computes in fp32 throughout). */
+ * convolution multiplies the hi planes only (one MFMA per product); 3: hi/lo planes, three MFMAs; 2: hi/lo planes of the weights,
+ * hi plane of the activations (a_hi w_hi + a_hi w_lo: the input is rounded to fp16 once, the weights are exact to 22 bits --
+ * half of the layer's rounding variance for two thirds of the 3-MFMA cost).  Layers that were never set follow their group's
+ * bit in dptx_config.x3_groups.  Tensors between layers carry a lo plane exactly where a 3-MFMA consumer reads it, so every
+ * assignment is valid.  With x3_groups = 0 dptx_create installs the default table (oracle/precision_layers.py);
+ * DPTX_FLAG_GROUP_POLICY suppresses it.  (Measured option outside the default: "scratch.output_conv.0.weight" = 2 is +3.9 %
+ * throughput for a worst-case deviation of 7.6e-4 instead of 6.3e-4 over a 32-image batch.)  May be called at any time before a forward; does not
+ * touch the packed weights.  The reference has no counterpart (it computes in fp32 throughout). */
 int dptx_set_layer_precision(dptx_handle h, const char* conv_weight_key, int32_t mfmas);
 
 /* fp8 dtype: activation scales.  Every tensor that has an e4m3 copy (the inputs of the decoder's fp8 convolutions) is
@@ -282,7 +285,8 @@ int dptx_op_conv(int32_t dtype, const void* X, const void* Wt, const float* bias
                  int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
                  int32_t Wo, int32_t a_relu, int32_t act, void* stream);
 /* the same convolution with the plane switches of the MIXED dtype's per-layer policy (kernels.h GemmParams::epi2 /
- * c_hi_only / r1_hi_only): epi2 = 1 with dtype FP16 multiplies the hi planes only but reads R and writes Y as hi/lo pairs */
+ * c_hi_only / r1_hi_only / a_hi_only): epi2 = 1 with dtype FP16 multiplies the hi planes only but reads R and writes Y as hi/lo
+ * pairs; epi2 = 2 with dtype FP16X3 is the 2-MFMA form (both planes of Wt, the hi plane of X only) */
 int dptx_op_conv_planes(int32_t dtype, const void* X, const void* Wt, const float* bias, const void* R, void* Y, int32_t B,
                         int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad_t,
                         int32_t pad_l, int32_t Ho, int32_t Wo, int32_t a_relu, int32_t act, int32_t epi2, int32_t c_hi_only,

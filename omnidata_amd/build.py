@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdptx.so")
-SOURCES = ["gemm.hip", "gemm_fp16.hip", "gemm_fp16e.hip", "gemm_x3.hip", "gemm_fp8.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip", "prepost.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "gemm_fp16.hip", "gemm_fp16e.hip", "gemm_x3.hip", "gemm_x2.hip", "gemm_fp8.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip", "prepost.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_impl.h", os.path.join("..", "..", "include", "dptx.h")]
 # Per-source compiler flags.  norm.hip / misc.hip (HBM-bound glue) are built without packed fp32 arithmetic: hipcc's SLP
 # vectoriser otherwise emits v_pk_add_f32 / v_pk_fma_f32 with op_sel swizzles there (low lane reading a high dword), the

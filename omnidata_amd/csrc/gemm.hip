@@ -53,7 +53,7 @@ hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
   if (mode == MODE_BF16) return p.epi2 ? hipErrorInvalidValue : launch_gemm_16(DT_BF16, p, stream);
   if (mode == MODE_FP16) return p.epi2 ? launch_gemm_fp16e(p, stream) : launch_gemm_16(DT_FP16, p, stream);
   if (mode == MODE_BF16X3) return launch_gemm_x3(DT_BF16, p, stream);
-  if (mode == MODE_FP16X3) return launch_gemm_x3(DT_FP16, p, stream);
+  if (mode == MODE_FP16X3) return p.a_hi_only ? launch_gemm_x2(p, stream) : launch_gemm_x3(DT_FP16, p, stream);
   return hipErrorInvalidValue;
 }
 

@@ -77,7 +77,7 @@ __device__ __forceinline__ float ln_fold_fma(float acc, float mu, float rstd, fl
 }
 
 // ----------------------------------------------------------------------------- shared pieces
-template <int DT, int TM, int TN, bool RELU_A, int PL = 1, int HK = BK / 16>
+template <int DT, int TM, int TN, bool RELU_A, int PL = 1, int HK = BK / 16, int XT = 3>
 __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_lo, int b_lo, int wm, int wn, int lr, int lh,
                                          f32x16_t (&acc)[TM][TN]) {
   // a_lo / b_lo: byte distance of the lo-plane tiles inside the stage (PL == 2)
@@ -157,6 +157,8 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
     // hi/lo planes, 3 MFMAs per product.  The fragment reads run one k-step ahead of the MFMAs (two fragment sets): the
     // 2 (TM + TN) ds_read_b128 of k-step ks+1 are in flight under the 3 TM TN MFMAs of k-step ks
     // (DPTX_X3_NOPIPE: read, then multiply, per k-step -- the round-1 form, for A/B runs)
+    // XT == 2 (GemmParams::a_hi_only): the activations contribute their hi plane only -- a_hi w_lo + a_hi w_hi, two MFMAs;
+    // the A lo tile is neither loaded nor read
     u32x4_t af[2][TM], bf[2][TN], al[2][TM], bl[2][TN];
     auto read = [&](int s_, int ks) {
       const int chunk = 2 * ks + lh;
@@ -165,7 +167,7 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
         const int row = wm * (TM * 32) + i * 32 + lr;
         const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
         af[s_][i] = *(const u32x4_t*)(sa + off);
-        al[s_][i] = *(const u32x4_t*)(sa + a_lo + off);
+        if (XT == 3) al[s_][i] = *(const u32x4_t*)(sa + a_lo + off);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -178,10 +180,13 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
     auto mma = [&](int s_) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        if (RELU_A) relu8_planes(af[s_][i], al[s_][i]);
+        if (RELU_A) {
+          if (XT == 3) relu8_planes(af[s_][i], al[s_][i]);
+          else af[s_][i] = relu8(af[s_][i]);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {  // small cross terms first, then the leading term
-          acc[i][j] = T16<DT>::mfma32(al[s_][i], bf[s_][j], acc[i][j]);
+          if (XT == 3) acc[i][j] = T16<DT>::mfma32(al[s_][i], bf[s_][j], acc[i][j]);
           acc[i][j] = T16<DT>::mfma32(af[s_][i], bl[s_][j], acc[i][j]);
           acc[i][j] = T16<DT>::mfma32(af[s_][i], bf[s_][j], acc[i][j]);
         }
@@ -571,7 +576,7 @@ constexpr unsigned OOB = 0x80000000u;  // >= any buffer size we bind (a_bytes < 
 // kernel is the per-layer precision policy's "single-pass compute, two-plane tensors": a layer that multiplies hi planes
 // only may still read the lo planes of its residuals and write a lo plane for a 3-MFMA consumer
 // (GemmParams::c_hi_only / r1_hi_only / r2_hi_only switch the individual planes off).
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A, int PL, int PLE = PL>
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool RELU_A, int PL, int PLE = PL, int XT = 3>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_glds_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer/LDS-DMA builtins exist only in the device pass
   constexpr int NT = 64 * WAVES_M * WAVES_N;  // 256 threads (2 blocks/CU), or 512 for the 256x256 tile (1 block/CU)
@@ -658,7 +663,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
       const unsigned vo = valid ? a_off[i] + tap_ : OOB;                                                           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(sa_ + i * PASS_BYTES), 16, vo, 0, \
                                                0, 0);                                                              \
-      if (PL == 2)                                                                                                 \
+      if (PL == 2 && XT == 3)                                                                                      \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcAl, (__attribute__((address_space(3))) void*)(sa_ + A_LO + i * PASS_BYTES), \
                                                  16, vo, 0, 0, 0);                                                 \
     }                                                                                                              \
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PL == 2 ? 1 : 2) void gemm_
     const char* sa = smem + (kt & 1) * STAGE_BYTES;
     if (kt + 1 < nk) DPTX_ISSUE_TILE((kt + 1) & 1, (kt + 1) * BK);
     DPTX_STAMP(1);
-    mma_tile<DT, TM, TN, RELU_A, PL, HK>(sa, sa + B_BASE, A_LO, B_LO, wm, wn, lr, lh, acc);
+    mma_tile<DT, TM, TN, RELU_A, PL, HK, XT>(sa, sa + B_BASE, A_LO, B_LO, wm, wn, lr, lh, acc);
     DPTX_STAMP(2);
   }
 #ifdef DPTX_TRACE
@@ -1365,7 +1370,7 @@ static void choose_xcd_grid(const GemmParams& p, int tiles_m, int tiles_n, int& 
 #include "experiments/gemm_experiments_dispatch.h"
 #endif
 
-template <int DT, int PL, int BM, int BN, int WM_, int WN_, int PLE = PL>
+template <int DT, int PL, int BM, int BN, int WM_, int WN_, int PLE = PL, int XT = 3>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
   GemmParams q = p;
@@ -1426,11 +1431,11 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   } else
   if (glds_ok && (PL == 2 || gemm_variant() != 1)) {
     if (p.a_relu) {
-      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL, PLE>;
+      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, true, PL, PLE, XT>;
       set_smem_attr(k, smem);
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     } else {
-      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL, PLE>;
+      auto k = gemm_glds_kernel<DT, BM, BN, WM_, WN_, false, PL, PLE, XT>;
       set_smem_attr(k, smem);
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * WM_ * WN_), smem, stream, q);
     }
@@ -1456,7 +1461,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <int DT, int PL, int PLE = PL>
+template <int DT, int PL, int PLE = PL, int XT = 3>
 static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   // tile choice: widest tile that still yields >= ~2 blocks per CU (256 CUs); N must divide.
   const long long m128 = (p.M + 127) / 128, m256 = (p.M + 255) / 256;
@@ -1469,9 +1474,9 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
   static int forced = -1;  // DPTX_TILE=128 disables the 256x256 tile; 12864 / 6464 force a tile shape (tools/gemm_bench.py)
   if (forced < 0) { const char* t = getenv("DPTX_TILE"); forced = t ? atoi(t) : 0; }
   {
-    if (forced == 128128 && p.N % 128 == 0) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE>(p, stream);
-    if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE>(p, stream);
-    if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE>(p, stream);
+    if (forced == 128128 && p.N % 128 == 0) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE, XT>(p, stream);
+    if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE, XT>(p, stream);
+    if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE, XT>(p, stream);
   }
 #ifdef DPTX_EXPERIMENTS
   {
@@ -1493,23 +1498,23 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
       const double fill256 = (double)t256 / (double)(r256 * cu1), fill128 = (double)t128 / (double)(r128 * cu2);
       static double adv = -1.0;  // DPTX_PP_ADV: the per-tile advantage assumed for the 256x256 kernel (A/B runs)
       if (adv < 0.0) { const char* e = getenv("DPTX_PP_ADV"); adv = e ? atof(e) : 1.5; }
-      if (t256 >= 200 * sh && fill256 * adv >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4, PLE>(p, stream);
+      if (t256 >= 200 * sh && fill256 * adv >= fill128) return launch_cfg<DT, PL, 256, 256, 2, 4, PLE, XT>(p, stream);
     }
   }
   if constexpr (PL == 2) {
     // 3-MFMA modes are one block per CU (two planes of two stages = 128 KB of LDS); eight waves (2 x 4, wave tile
     // 64 x 32) instead of four put two waves on every SIMD, so that one's fragment reads overlap the other's MFMAs:
     // GEMM family 32.7 -> 30.5 ms per fp16x3 forward (profiles/r02_experiments.md)
-    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200 * shs) return launch_cfg<DT, PL, 128, 128, 2, 4, PLE>(p, stream);
+    if (p.N % 128 == 0 && m128 * (p.N / 128) >= 200 * shs) return launch_cfg<DT, PL, 128, 128, 2, 4, PLE, XT>(p, stream);
   }
   // (row_stats -- the producer side of the LayerNorm fold -- reduces 128-column blocks inside a tile: never narrower tiles)
   // 128x128 from 256 tiles up (one block on every CU): at 288 tiles (M = 18432, N = 256) it still beats 576 tiles of
   // 128x64 by 2..10 %, whose second round is nearly empty
-  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 * shs || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE>(p, stream);
-  if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1, PLE>(p, stream);
-  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448 * shs) return launch_cfg<DT, PL, 256, 64, 4, 1, PLE>(p, stream);
-  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448 * shs) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE>(p, stream);
-  if (p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE>(p, stream);
+  if (p.N % 128 == 0 && (m128 * (p.N / 128) >= 256 * shs || p.row_stats != nullptr)) return launch_cfg<DT, PL, 128, 128, 2, 2, PLE, XT>(p, stream);
+  if (p.N == 32) return launch_cfg<DT, PL, 256, 32, 4, 1, PLE, XT>(p, stream);
+  if (PL == 1 && p.N % 64 == 0 && p.N < 128 && m256 * (p.N / 64) >= 448 * shs) return launch_cfg<DT, PL, 256, 64, 4, 1, PLE, XT>(p, stream);
+  if (p.N % 64 == 0 && m128 * (p.N / 64) >= 448 * shs) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE, XT>(p, stream);
+  if (p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE, XT>(p, stream);
   return hipErrorInvalidValue;
 }
 
@@ -1519,6 +1524,7 @@ hipError_t launch_gemm_16(int dt, const GemmParams& p, hipStream_t stream);   //
 hipError_t launch_gemm_fp16(const GemmParams& p, hipStream_t stream);         // gemm_fp16.hip: DT_FP16, one plane
 hipError_t launch_gemm_fp16e(const GemmParams& p, hipStream_t stream);        // gemm_fp16e.hip: DT_FP16, one plane, two-plane epilogue
 hipError_t launch_gemm_x3(int dt, const GemmParams& p, hipStream_t stream);   // gemm_x3.hip:  DT_BF16 / DT_FP16, hi/lo planes
+hipError_t launch_gemm_x2(const GemmParams& p, hipStream_t stream);           // gemm_x2.hip:  DT_FP16, hi/lo planes, A hi only (2 MFMAs)
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream);          // gemm_fp8.hip: e4m3
 
 }  // namespace dptx

@@ -43,6 +43,10 @@ struct GemmParams {
   // fp16 kernel -- residuals are read with their lo planes and C is written as a hi/lo pair; *_hi_only (two-plane epilogues,
   // also of the 3-MFMA kernels) switch off the lo plane of C / R1 / R2 individually
   int epi2, c_hi_only, r1_hi_only, r2_hi_only;
+  // a_hi_only (fp16 hi/lo-plane kernels): TWO MFMAs per product -- a_hi w_hi + a_hi w_lo; the lo plane of A is not read
+  // (per-layer precision 2 of dptx_set_layer_precision: the weights keep their full precision, the activations are rounded
+  // to fp16 once)
+  int a_hi_only;
   int xcd_m, xcd_n;  // XCD grid of the tile partition (filled in by launch_gemm)
   float cu_share, cu_share_small;  // part of the chip this launch can count on, for the 256x256 rule / the narrow-tile
                                    // thresholds (filled in by launch_gemm from gemm_set_cu_share; 0 = 1)
@@ -126,7 +130,7 @@ hipError_t launch_stem_conv(int mode, const void* x, int io, const void* Wt, voi
 // bilinear x2 align_corners=True on NHWC 16-bit
 // Y8 (optional): e4m3 copy of the output times q_scale, 1 byte per element, for an fp8 convolution downstream
 hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream,
-                             void* Y8 = nullptr, float q_scale = 1.0f);
+                             void* Y8 = nullptr, float q_scale = 1.0f, bool out_hi_only = false);
 // fp8 calibration: atomicMax(*amax_bits, bits of max |x| (relu: max(x, 0)) over n 16-bit elements); *amax_bits starts at 0
 hipError_t launch_amax(int mode, const void* X, size_t n, int relu, unsigned* amax_bits, hipStream_t stream);
 

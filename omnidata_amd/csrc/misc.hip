@@ -31,7 +31,7 @@ void ensure_dyn_smem(const void* kernel, size_t bytes) {
 template <int DT, int PL>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restrict__ X, uint16_t* __restrict__ Y,
                                                          uint8_t* __restrict__ Y8, float q_scale, int B, int H, int W, int C,
-                                                         int cshift, long long plane) {
+                                                         int cshift, long long plane, int out_hi_only) {
   const int Ho = 2 * H, Wo = 2 * W, cvec = C >> 3;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Wo * cvec) return;
@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restr
   load8f<DT, PL>(img + (y1 * W + x1) * C, plane, d);
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = bilerp(a[e], bb[e], c[e], d[e], lx0, lx1, ly0, ly1);
-  store8f<DT, PL>(Y + ((long long)blockIdx.y * Wo + ox) * C + v * 8, plane, o);
+  // (out_hi_only: two planes in, the hi plane out -- the same rounding as the hi half of the pair)
+  if (PL == 2 && out_hi_only) store8f<DT, 1>(Y + ((long long)blockIdx.y * Wo + ox) * C + v * 8, plane, o);
+  else store8f<DT, PL>(Y + ((long long)blockIdx.y * Wo + ox) * C + v * 8, plane, o);
   if (Y8 != nullptr) {  // e4m3 copy for an fp8 conv (times the tensor's calibrated power-of-two scale)
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] *= q_scale;
@@ -61,14 +63,14 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const uint16_t* __restr
 }
 
 hipError_t launch_upsample2x(int mode, const void* X, void* Y, int B, int H, int W, int C, Planes pl, hipStream_t stream,
-                             void* Y8, float q_scale) {
+                             void* Y8, float q_scale, bool out_hi_only) {
   const int cvec = C / 8;
   if (C % 8 != 0 || (cvec & (cvec - 1)) != 0 || (long long)H * W * C >= (1ll << 31)) return hipErrorInvalidValue;
   int cshift = 0;
   while ((1 << cshift) < cvec) ++cshift;
   dim3 grid((2 * W * cvec + 255) / 256, B * 2 * H);
   DPTX_DISPATCH_MODE(mode, hipLaunchKernelGGL((upsample2x_kernel<DT, PL>), grid, dim3(256), 0, stream, (const uint16_t*)X,
-                                              (uint16_t*)Y, (uint8_t*)Y8, q_scale, B, H, W, C, cshift, pl.act));
+                                              (uint16_t*)Y, (uint8_t*)Y8, q_scale, B, H, W, C, cshift, pl.act, (int)out_hi_only));
   return hipGetLastError();
 }
 

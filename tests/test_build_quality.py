@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "omnidata_amd", "csrc")
 
 
-ALL = ["gemm.hip", "gemm_fp16.hip", "gemm_fp16e.hip", "gemm_x3.hip", "gemm_fp8.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip",
+ALL = ["gemm.hip", "gemm_fp16.hip", "gemm_fp16e.hip", "gemm_x3.hip", "gemm_x2.hip", "gemm_fp8.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip",
        "prepost.hip"]
 _cache = {}
 
@@ -50,6 +50,7 @@ def test_no_scratch_no_spills(src, tmp_path):
         want = {"gemm.hip": ["v_mfma_f32_32x32x16_bf16"], "gemm_fp16.hip": ["v_mfma_f32_32x32x16_f16"],
                 "gemm_fp16e.hip": ["v_mfma_f32_32x32x16_f16"],
                 "gemm_x3.hip": ["v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16"],
+                "gemm_x2.hip": ["v_mfma_f32_32x32x16_f16"],
                 "gemm_fp8.hip": ["v_mfma_scale_f32_32x32x64_f8f6f4"]}[src]
         assert all(w in s for w in want)
         assert re.search(r"buffer_load_dwordx4 .* lds", s), "direct-to-LDS staging missing"
