@@ -154,7 +154,7 @@ def main():
         # figure is the committed rocprofv3 measurement of this very command (profiles/README.md), scaled
         # from its batch to this one; null when no measurement is committed for the dtype.
         traffic = None
-        for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json"):  # newest committed round wins
+        for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json", "r04_pmc_traffic.json"):  # newest committed round wins
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and args.dtype == "bf16" and not large:
                 tj = json.load(open(tpath))
