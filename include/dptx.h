@@ -326,8 +326,9 @@ int dptx_debug_arena_checksums(dptx_handle h, void* out_dev, int32_t capacity, v
  * forwards: dev_buf[launch * 5 + buffer] (uint64 device memory, capacity entries; launch 0 = after the cls rows, then qkv /
  * attention / proj / fc1 / fc2 per block).  NULL switches it off. */
 int dptx_debug_set_launch_sums(dptx_handle h, void* dev_buf, int32_t capacity);
-/* Debug / tests: process-wide switches of the 256x256 GEMM kernel's launch form -- 1: staged epilogue instead of the
- * register-direct one, 2: one block per tile instead of the persistent tile loop.  Results do not depend on them. */
+/* Debug / tests: switches (per calling host thread) of the 256x256 GEMM kernel's launch form -- 1: staged epilogue instead of the
+ * register-direct one, 2: one block per tile instead of the persistent tile loop, 4: the lockstep loop instead of the ping-pong
+ * schedule in the two-plane 128x128 kernel.  Results do not depend on them. */
 int dptx_debug_set_gemm_flags(int32_t flags);
 /* NHWC conv on OCP e4m3 operands (the fp8 dtype's convolution): X8[B,H,W,Cin] and Wt8[Cout][k][k][Cin] are e4m3 bytes
  * (Cin % 128 == 0), fp32 accumulate on the block-scaled fp8 MFMA at unit scale; Y = act(out_scale * conv + bias) (+R) in

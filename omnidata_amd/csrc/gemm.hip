@@ -16,9 +16,11 @@ void gemm_params_dense(GemmParams& p, int M, int N, int K) {
   p.a_bytes = (long long)M * K * 2;
 }
 
-static long long* g_trace = nullptr;
+// debug state is per host thread, like the tile-share state below: a test thread that switches launch forms or records a
+// trace does not change what another thread's forwards launch
+static thread_local long long* g_trace = nullptr;
 void gemm_set_trace(long long* dev_buf) { g_trace = dev_buf; }
-static int g_debug_flags = 0;
+static thread_local int g_debug_flags = 0;
 void gemm_set_debug_flags(int flags) { g_debug_flags = flags; }
 static thread_local float g_cu_share = 1.0f, g_cu_share_small = 1.0f;
 void gemm_set_cu_share(float share, float share_small) {

@@ -1171,6 +1171,166 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
 }
 
+// ------------------------------------------------------------------- ping-pong 128x128 kernel for hi/lo planes
+// Round 4.  In the parity mode the two-plane gemm_glds_kernel<fp16, 128, 128, 2, 4> is 37 % of the forward (59 launches,
+// 8.2 ms: profiles/r04_kernel_trace_stats_mixed.txt); its k-loop is the lockstep one -- all eight waves issue their eight DMA
+// pieces, then all multiply: 1.7 us per k-tile on output_conv.0 for 1536 cycles of MFMA work per SIMD.  A two-plane stage of
+// a 128x128 tile is 512 LDS rows = 64 pieces of 1 KB, exactly what a one-plane stage of the 256x256 tile is, so the schedule
+// of gemm_pp_kernel carries over: the two wave groups (wm = 0 / 1: rows 0..63 / 64..127, one wave of each on every SIMD;
+// wave tile 64 x 32, 24 MFMAs per k-tile) run half an iteration apart, two barriers per k-tile,
+//     slot 1:  group 0 issues W hi / lo and A rows 64..127 hi / lo of tile t+1 (12 pieces per wave)  |  group 1 multiplies tile t
+//     slot 2:  group 0 multiplies tile t                         |  group 1 issues A rows 0..63 hi / lo of tile t+1 (4 pieces)
+// with the same who-reads-what-first argument.  Stage image: [A0 hi | A0 lo | A1 hi | A1 lo | W hi | W lo] (64 + 64 + 64 + 64 +
+// 128 + 128 rows).  One block per tile (no persistent loop), the epilogue is gemm_glds_kernel's.  XT == 2 (a_hi_only): the A lo
+// pieces are not issued (10 + 2 per wave) and not read.  DPTX_PP2=0: the lockstep kernel (A/B runs; bit-identical results --
+// the MFMAs of an accumulator run in the same order).  Same box, single-stream per-launch events: output_conv.0 2.15 -> 1.92 ms,
+// layer2_rn 0.538 -> 0.480, the ResNetV2 3x3 / 1x1 convolutions -8 ... -13 %; 0.63 ms of the 21.8 ms launch sum, parity mode
+// 1646 -> 1667 img/s in the two-stream schedule.
+template <int DT, bool RELU_A, int XT = 3>
+__global__ __launch_bounds__(512, 1) void gemm_pp2_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 128, NT = 512, TM = 2, TN = 1, PL = 2;
+  constexpr int Q = 64 * 128;              // bytes of a 64-row operand tile
+  constexpr int STAGE = 8 * Q;             // 64 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm = wave group
+  const int lr = lane & 31, lh = lane >> 5;
+  const int t = tid & 255, kc = t & 7, r0 = t >> 3;   // loader coordinates inside the group: LDS chunk kc of rows r0 + 32 i
+  const int sc = kc ^ ((r0 >> 1) & 7);
+  const int wq = wave & 3;                  // rows 8 wq .. 8 wq + 7 of every 32-row pass
+  auto a_ptr = [&](int b, int g) -> char* { return smem + b * STAGE + g * 2 * Q; };   // [hi 64 rows | lo 64 rows] of group g
+  auto w_ptr = [&](int b) -> char* { return smem + b * STAGE + 4 * Q; };              // [hi 128 rows | lo 128 rows]
+
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+    const int tn_per = tiles_n / p.xcd_n, tm_per = (tiles_m + p.xcd_m - 1) / p.xcd_m;
+    const int mt = (x / p.xcd_n) * tm_per + l / tn_per;
+    const int nt = (x % p.xcd_n) * tn_per + l % tn_per;
+    if (mt >= tiles_m || l >= tm_per * tn_per) return;
+    m0 = mt * BM;
+    n0 = nt * BN;
+  }
+  // group 0 loads the A rows of group 1 and vice versa (who reads what first, above)
+  const int a_row0 = wm == 0 ? 64 : 0;
+  int a_iy0[2], a_ix0[2];
+  unsigned a_off[2], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + a_row0 + r0 + 32 * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    int rem, ox;
+    const int img = row_div(mm, p.a_rpi, p.a_rpi_rcp, false, rem);
+    const int oy = row_div(rem, p.Wout, p.wout_rcp, false, ox);
+    a_iy0[i] = ok ? oy * p.stride - p.pad_t : -0x40000000;
+    a_ix0[i] = ox * p.stride - p.pad_l;
+    const unsigned e = (unsigned)img * (unsigned)p.a_img_stride + (unsigned)p.a_off +
+                       (unsigned)(a_iy0[i] * p.Win + a_ix0[i]) * (unsigned)p.a_pix_stride + (unsigned)(sc * 8);
+    a_off[i] = ok ? e * 2u : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w_off[j] = ((unsigned)(n0 + r0 + 32 * j) * (unsigned)p.ldw + (unsigned)(sc * 8)) * 2u;
+  const int w_bytes = (int)((long long)p.N * p.ldw * 2);
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcAl =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((uint16_t*)const_cast<void*>(p.A) + p.planes.act), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcWl =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((uint16_t*)const_cast<void*>(p.W) + p.planes.w), 0, w_bytes, 0x00020000);
+
+  int ky = 0, kx = 0, c0 = 0, kyw = 0, kxw = 0, c0w = 0;   // tap state of this group's A pieces / of the W pieces
+#define DPTX_P2_NEXT(KY, KX, C0)                                                                                   \
+  do {                                                                                                             \
+    if (p.k_tap_fast) {                                                                                            \
+      if (++KX == p.ksz) { KX = 0; if (++KY == p.ksz) { KY = 0; C0 += BK; } }                                      \
+    } else {                                                                                                       \
+      C0 += BK;                                                                                                    \
+      if (C0 >= p.Cin) { C0 = 0; if (++KX == p.ksz) { KX = 0; ++KY; } }                                            \
+    }                                                                                                              \
+  } while (0)
+  // this group's A pieces (the OTHER group's rows) of the k-tile at (ky, kx, c0) into DST = [hi 64 rows | lo 64 rows]
+#define DPTX_P2_ISSUE_A(DST)                                                                                       \
+  do {                                                                                                             \
+    char* d_ = (DST) + wq * 1024;                                                                                  \
+    const unsigned tap_ = (unsigned)(((ky * p.Win + kx) * p.a_pix_stride + c0) * 2);                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+      const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                                                            \
+      const bool valid = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);                     \
+      const unsigned vo = valid ? a_off[i] + tap_ : OOB;                                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (__attribute__((address_space(3))) void*)(d_ + 32 * i * 128), 16, vo, 0, 0, 0); \
+      if (XT == 3)                                                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcAl, (__attribute__((address_space(3))) void*)(d_ + Q + 32 * i * 128), 16, vo, 0, 0, 0); \
+    }                                                                                                              \
+    DPTX_P2_NEXT(ky, kx, c0);                                                                                      \
+  } while (0)
+  // W passes J0 .. J0 + NJ - 1 of [hi: 0..3 | lo: 4..7] of the k-tile at (kyw, kxw, c0w) into the 256-row image at DST
+#define DPTX_P2_ISSUE_W(DST, J0, NJ)                                                                               \
+  do {                                                                                                             \
+    char* d_ = (DST) + wq * 1024;                                                                                  \
+    const unsigned wk_ = (unsigned)((((kyw * p.ksz + kxw) * p.Cin) + c0w) * 2);                                    \
+    _Pragma("unroll") for (int j = (J0); j < (J0) + (NJ); ++j) {                                                   \
+      if (j < 4)                                                                                                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (__attribute__((address_space(3))) void*)(d_ + 32 * j * 128), 16, \
+                                                 w_off[j & 3] + wk_, 0, 0, 0);                                     \
+      else                                                                                                         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcWl, (__attribute__((address_space(3))) void*)(d_ + 32 * j * 128), 16, \
+                                                 w_off[j & 3] + wk_, 0, 0, 0);                                     \
+    }                                                                                                              \
+  } while (0)
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  const int nk = p.K / BK;
+  // first k-tile into stage 0: nobody multiplies before all of it has landed, so the pieces are split evenly -- group 0 the
+  // hi plane of W, group 1 the lo plane, each group the A rows it loads in the loop as well
+  if (wm == 0) DPTX_P2_ISSUE_W(w_ptr(0), 0, 4);
+  else DPTX_P2_ISSUE_W(w_ptr(0), 4, 4);
+  DPTX_P2_NEXT(kyw, kxw, c0w);
+  DPTX_P2_ISSUE_A(a_ptr(0, wm ^ 1));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // two straight-line loops, one per group (an MFMA under a per-slot branch turns the accumulators into a phi)
+  if (wm == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* sa = a_ptr(kt & 1, 0);
+      const char* sb = w_ptr(kt & 1);
+      if (kt + 1 < nk) {                                   // slot 1: the DMA
+        DPTX_P2_ISSUE_W(w_ptr((kt + 1) & 1), 0, 8);
+        DPTX_P2_NEXT(kyw, kxw, c0w);
+        DPTX_P2_ISSUE_A(a_ptr((kt + 1) & 1, 1));
+      }
+      asm volatile("s_barrier" ::: "memory");
+      mma_tile<DT, TM, TN, RELU_A, PL, BK / 16, XT>(sa, sb, Q, 128 * 128, 0, wn, lr, lh, acc);   // slot 2
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // what group 1 reads in its next slot has landed
+      asm volatile("s_barrier" ::: "memory");
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* sa = a_ptr(kt & 1, 1);
+      const char* sb = w_ptr(kt & 1);
+      mma_tile<DT, TM, TN, RELU_A, PL, BK / 16, XT>(sa, sb, Q, 128 * 128, 0, wn, lr, lh, acc);   // slot 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // its DMA of the previous slot 2 (group 0's rows of THIS tile)
+      asm volatile("s_barrier" ::: "memory");
+      if (kt + 1 < nk) DPTX_P2_ISSUE_A(a_ptr((kt + 1) & 1, 0));   // slot 2
+      asm volatile("s_barrier" ::: "memory");
+    }
+  }
+#undef DPTX_P2_ISSUE_W
+#undef DPTX_P2_ISSUE_A
+#undef DPTX_P2_NEXT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // all waves finished reading the stages: re-use LDS for the C tile
+  epilogue<DT, BM, BN, TM, TN, 2, NT, 1>(p, smem, m0, n0, wm, wn, lr, lh, tid, acc);
+#endif
+}
+
 #ifdef DPTX_EXPERIMENTS
 #include "experiments/gemm_experiments.h"
 #endif
@@ -1419,6 +1579,19 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       }
       if (p.a_relu) go(gemm_pp_kernel<DT, true, PLE>);
       else go(gemm_pp_kernel<DT, false, PLE>);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (DT != DT_FP8 && PL == 2 && PLE == 2 && BM == 128 && BN == 128 && WM_ == 2 && WN_ == 4) {
+    // the two-plane 128x128 tile: ping-pong schedule of the two wave groups (gemm_pp2_kernel).  DPTX_PP2=0: lockstep loop
+    static int pp2 = -1;
+    if (pp2 < 0) { const char* e = getenv("DPTX_PP2"); pp2 = e ? atoi(e) : 1; }
+    // (not with the pre-activation on the A fragments: its VALU work sits inside the MFMA slot, and the two RCU convolutions
+    // that have it were 8-9 % SLOWER than with the lockstep loop: profiles/r04_experiments.md)
+    if (pp2 && !(p.debug_flags & 4) && p.K >= 2 * BK && !p.a_relu) {
+      auto k = gemm_pp2_kernel<DT, false, XT>;
+      set_smem_attr(k, smem);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(512), smem, stream, q);
       return hipGetLastError();
     }
   }

@@ -81,7 +81,7 @@ struct GemmParams {
   int ln_nblk;
   float ln_eps, ln_inv_dim;
   long long* trace;  // debug: s_memtime stamps of block 0 (dptx_debug_set_trace); null in production
-  int debug_flags;   // debug (dptx_debug_set_gemm_flags): 1 = staged epilogue everywhere, 2 = one block per tile
+  int debug_flags;   // debug (dptx_debug_set_gemm_flags): 1 = staged epilogue everywhere, 2 = one block per tile, 4 = lockstep two-plane 128x128 kernel
   float a_rpi_rcp, wout_rcp;  // 1 / a_rpi, 1 / Wout (filled in by launch_gemm: row -> (image, y, x) without integer division)
 };
 

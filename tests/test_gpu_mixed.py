@@ -272,6 +272,36 @@ def test_single_pass_conv_with_two_plane_epilogue():
         ar.release()
 
 
+@pytest.mark.parametrize("epi2", [0, 2])
+def test_two_plane_ping_pong_kernel_equals_the_lockstep_kernel(epi2):
+    """gemm_pp2_kernel (round 4: ping-pong schedule of the two wave groups in the two-plane 128x128 tile) runs the MFMAs of
+    every accumulator in the same order as the lockstep gemm_glds_kernel: bit-identical planes, 3- and 2-MFMA form, on a shape
+    with padding taps, a ragged last tile (M % 128 != 0) and a residual."""
+    lib = load_library()
+    B, H, W, C, N = 3, 96, 90, 256, 256
+    ar = PlaneArena(B * H * W * (C + 3 * N) + N * 9 * C + 8192, dtype=torch.float16)
+    try:
+        X = ar.put(g(B, H, W, C, seed=41))
+        Wt = ar.put(g(N, 3, 3, C, scale=(9 * C) ** -0.5, seed=42))
+        R = ar.put(g(B, H, W, N, seed=43))
+        bias = torch.randn(N, device=DEV) * 0.1
+        outs = []
+        for flags in (0, 4):
+            assert lib.dptx_debug_set_gemm_flags(flags) == 0
+            Y = ar.empty(B, H, W, N)
+            rc = lib.dptx_op_conv_planes(F16X3, ptr(X), ptr(Wt), ptr(bias), ptr(R), ptr(Y), B, H, W, C, N, 3, 1, 1, 1, H, W, 0, 1, epi2, 0, 0, stream())
+            assert rc == 0
+            outs.append(ar.value(Y).clone())
+        lib.dptx_debug_set_gemm_flags(0)
+        assert torch.equal(outs[0], outs[1])
+        ref = F.relu(F.conv2d(ar.value(X).permute(0, 3, 1, 2) if epi2 == 0 else X.double().permute(0, 3, 1, 2),
+                              ar.value(Wt).permute(0, 3, 1, 2), bias.double(), padding=1)).permute(0, 2, 3, 1) + ar.value(R)
+        assert rel_err(outs[0], ref) < TOL
+    finally:
+        lib.dptx_debug_set_gemm_flags(0)
+        ar.release()
+
+
 @pytest.mark.parametrize("B,H,a_relu,N", [(3, 96, 0, 128), (3, 96, 1, 256), (2, 48, 1, 256), (2, 48, 0, 64)])  # 128x128 (8 waves) x2, 64x64 x2
 def test_two_mfma_conv_rounds_only_its_input(B, H, a_relu, N):
     """Per-layer precision 2 (gemm_impl.h XT == 2, GemmParams::a_hi_only): both planes of the weights, the hi plane of the

@@ -2,7 +2,7 @@
 # end-of-round evidence (round 4): ONE full gpu suite on the final library (no -x), smoke, bench lines, rocprofv3 trace + PMC passes
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/final4
+O=$R/gpurun_out/${FINAL_DIR:-final4}
 mkdir -p $O
 export TMPDIR=/tmp
 python -c "from omnidata_amd.engine import load_library; print(load_library().dptx_version())" > $O/version.log 2>&1; cat $O/version.log
@@ -15,6 +15,10 @@ for cfg in "--dtype mixed" "--dtype fp16x3" "--dtype fp16" "--task depth" "--tas
 done
 timeout 300 python bench.py --dtype mixed --steps 10 --warmup 3 --no-cpu-baseline --no-also --parity-dtype none --profile-dump $O/launches_mixed.csv > /dev/null 2>&1
 DPTX_STREAMS=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also > $O/bench_1stream.log 2>&1; tail -1 $O/bench_1stream.log | cut -c1-120
+# same-box A/B of the two-plane ping-pong kernel (bit-identical results: tests/test_gpu_mixed.py)
+for V in 0 1 0 1; do
+  DPTX_PP2=$V timeout 300 python bench.py --dtype mixed --steps 10 --warmup 3 --no-cpu-baseline --no-also --parity-dtype none > $O/ab_pp2_$V.log 2>&1; echo "DPTX_PP2=$V: $(tail -1 $O/ab_pp2_$V.log | cut -c76-90)" | tee -a $O/ab_pp2.txt
+done
 timeout 400 python bench.py --backbone vitl16_384 --task depth --steps 8 --warmup 3 --no-also > $O/bench_vitl16.log 2>&1; tail -1 $O/bench_vitl16.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('vitl16', d['value'], d['roofline']['frac'], d['parity'])"
 timeout 300 python tools/gemm_bench.py --only cal.4096,cal.8192,vit.qkv,vit.proj,vit.fc1,vit.fc2,rcu@96,rcu@48,head.0,l2_rn,l3_rn,s2.c1,s2.c2,s2.c3 --iters 30 > $O/gemm_shapes.txt 2>&1; grep TF/s $O/gemm_shapes.txt | tail -16
 timeout 200 python tools/gpu/r4_headx3_bench.py > $O/headx3_bench.txt 2>&1; tail -3 $O/headx3_bench.txt
