@@ -4,13 +4,17 @@
 // Input  qkv[B*S][3*H*64] 16-bit, feature index = which*H*64 + head*64 + dim (timm's
 //        reshape(B,N,3,heads,64) packing); output out[B*S][H*64] 16-bit.
 // Grid   1-D, ceil(S/128) * B * H blocks (q-block slowest: K/V sharers stay on one XCD); 4 waves x 32 query rows.
-// Per 64-key tile (shared by the 4 waves through LDS):
-//   K  tile [64 keys][64 d]   row-major, 16-B chunks XOR-swizzled (same scheme as gemm.hip)
-//   V^T tile [64 d][64 keys]  transposed while staging (two adjacent keys per ds_write_b32),
-//                             same XOR swizzle keyed on the d row, key order permuted (bits 2<->3
-//                             within each 32-key half) so that the P^T accumulator registers of
-//                             the first MFMA are directly the B operand of the second one -- no
-//                             cross-lane movement of P.
+// Per 64-key tile (shared by the 4 waves through LDS; both operands travel by LDS-DMA, `buffer_load ... lds`: no staging
+// registers, no ds_write, no VALU -- round 4, below):
+//   K tile [64 keys][64 d]   row-major, 16-B chunks XOR-swizzled (same scheme as gemm.hip; the DMA image is lane-linear, so
+//                            the swizzle goes on the SOURCE chunk)
+//   V tile [64 keys][64 d]   row-major as well; the PV MFMA's A fragment (a d row, eight keys) is a COLUMN of it, read with
+//                            ds_read_b64_tr_b16: a 16-lane group reads 4 keys x 16 d (lane l' supplies the address of
+//                            V[key l'/4][d 4 (l' % 4) ..]) and lane l' receives V[4 keys][d l'] -- four consecutive keys of its
+//                            d row; two reads give the eight keys in the order of the P^T registers (element e -> key
+//                            (e & 3) + 8 (e >> 2) + 4 lh), so the P^T accumulators of the first MFMA are directly the B operand
+//                            of the second one.  Position chunk p of row r holds source chunk p ^ 4 ((r >> 1) & 1): the eight
+//                            rows one transposing read touches then fill two whole 256-byte bank rows.
 //   S^T[key][q] = mfma32x32x16(K, Q)   (swapped operands: a lane owns ONE query column, so the
 //                                       row max / row sum are in-lane + one lane^32 exchange)
 //   online softmax in fp32 (exp2 with the 1/8 scale folded into the exponent constant)
@@ -26,8 +30,9 @@ constexpr int ATT_K_BYTES = ATT_KT * 128;  // 8 KB
 constexpr int ATT_V_BYTES = ATT_D * 128;   // 8 KB
 constexpr int ATT_STAGE = ATT_K_BYTES + ATT_V_BYTES;
 
-__device__ __forceinline__ int vt_pos(int key) {  // swap bits 2 and 3
-  return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
+__device__ __forceinline__ uint4 lds_read16(const char* p) {
+  const u32x4_t v = *(const u32x4_t*)p;
+  return uint4{v.x, v.y, v.z, v.w};
 }
 
 // PL == 2 (bf16x3 / fp16x3 modes): q/k/v/p are hi+lo plane pairs and every product is 3 MFMAs
@@ -39,6 +44,12 @@ __device__ __forceinline__ int vt_pos(int key) {  // swap bits 2 and 3
 // 384x384 instead of ten tiles the last of which held ONE key; (b) the two 32-key halves of a tile go through QK^T
 // together (two independent MFMA chains instead of one dependent chain of four) and share ONE running-max update, one
 // alpha and at most one rescale of O per tile; (c) waves whose 32 queries all lie beyond S only stage K / V.
+//
+// Round 4 (tools/gpu/att_probe.py: the kernel with parts removed -- without the K / V staging 49 of 79 us, without the MFMAs 49,
+// without exp / sum / max 56, skeleton 24): the staging -- global load -> registers -> VALU transposition of V -> ten ds_write per
+// thread and tile -- was the largest single item.  K and V now travel by LDS-DMA and V is transposed by the fragment read
+// (ds_read_b64_tr_b16): 79.4 -> 62.8 us at op level, 158 -> 112 registers (four blocks per CU instead of three), results
+// bit-identical to the round-3 kernel.
 template <int DT, int PL>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                            int S, int H, int BH, long long plane) {
@@ -67,48 +78,55 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     if (PL == 2) ql[ks] = *(const uint4*)(qbase + plane + (row0 + qc) * ld + ks * 16 + lh * 8);
   }
 
-  // staging: thread t loads 16 B (d chunk t&7) of K for keys (t>>3), (t>>3)+32 and of V for the
-  // adjacent key pair 2*(t>>3), 2*(t>>3)+1 (adjacent keys stay adjacent under vt_pos).  Tile T holds keys 1 + 64 T ...
-  const int kc = tid & 7, kr = tid >> 3;
-  u32x4_t rk[2 * PL], rv[2 * PL];  // [plane][i]
+  // staging: per tile and plane wave w issues pieces 2w, 2w+1 of K and of V (a piece = 8 keys x 128 B, lane-linear: lane l
+  // writes chunk l & 7 of row l >> 3, so it fetches the source chunk that belongs there); keys >= S get an out-of-range buffer
+  // offset, which the hardware returns as zeros.  Tile T holds keys 1 + 64 T ...
   const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-#define ATT_LOAD_KV(T)                                                                        \
-  do {                                                                                        \
-    _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) {                                       \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
-        const int key = 1 + (T) * ATT_KT + kr + 32 * i;                                       \
-        const int vkey = 1 + (T) * ATT_KT + 2 * kr + i;                                       \
-        u32x4_t k4 = zero4, v4 = zero4;                                                       \
-        if (key < S) k4 = *(const u32x4_t*)(kbase + pl * plane + (row0 + key) * ld + kc * 8); \
-        if (vkey < S) v4 = *(const u32x4_t*)(vbase + pl * plane + (row0 + vkey) * ld + kc * 8); \
-        rk[pl * 2 + i] = k4;                                                                  \
-        rv[pl * 2 + i] = v4;                                                                  \
-      }                                                                                       \
-    }                                                                                         \
-  } while (0)
-#define ATT_STORE_KV(BUF)                                                                     \
-  do {                                                                                        \
-    _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) {                                       \
-      char* sk = smem + (BUF) * STAGE + pl * ATT_STAGE;                                       \
-      char* sv = sk + ATT_K_BYTES;                                                            \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                         \
-        const int row = kr + 32 * i;                                                          \
-        *(u32x4_t*)(sk + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rk[pl * 2 + i];        \
-      }                                                                                       \
-      const int key_l = 2 * kr;                                                               \
-      const int pos = (key_l & 32) | vt_pos(key_l & 31);                                      \
-      const u32x4_t w0 = rv[pl * 2], w1 = rv[pl * 2 + 1];                                     \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                         \
-        const uint32_t a = (e & 1) ? (w0[e >> 1] >> 16) : (w0[e >> 1] & 0xffffu);             \
-        const uint32_t c = (e & 1) ? (w1[e >> 1] >> 16) : (w1[e >> 1] & 0xffffu);             \
-        const int d = kc * 8 + e;                                                             \
-        *(uint32_t*)(sv + d * 128 + ((((pos >> 3) ^ ((d >> 1) & 7) ^ ((d >> 4) & 3))) << 4) + (pos & 7) * 2) = a | (c << 16); \
-      }                                                                                       \
-    }                                                                                         \
-  } while (0)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int qkv_bytes = (int)((long long)(BH / H) * S * ld * 2);   // < 2^31 (launch_attention)
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv), 0, qkv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkv) + (PL == 2 ? plane : 0), 0, qkv_bytes, 0x00020000);
+  auto dma_kv = [&](int T, int buf) {
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const int row = (wave * 2 + pc) * 8 + (lane >> 3);
+      const int key = 1 + T * ATT_KT + row;
+      const bool ok = key < S;
+      const unsigned rowoff = (unsigned)((row0 + key) * ld + head * ATT_D);
+      const unsigned koff = ok ? (rowoff + H * ATT_D + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2u : 0x80000000u;
+      const unsigned voff = ok ? (rowoff + 2 * H * ATT_D + (((lane & 7) ^ (4 * ((row >> 1) & 1))) << 3)) * 2u : 0x80000000u;
+      char* dst = smem + buf * STAGE + (wave * 2 + pc) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)dst, 16, koff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, (__attribute__((address_space(3))) void*)(dst + ATT_K_BYTES), 16, voff, 0, 0, 0);
+      if (PL == 2) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(dst + ATT_STAGE), 16, koff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (__attribute__((address_space(3))) void*)(dst + ATT_STAGE + ATT_K_BYTES), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+  // transposing V fragment reads: this lane's address inside the V tile for d block dt (the i-th 16-key block and the second
+  // half of the eight keys are immediate offsets: + 2048 i, + 1024)
+  const int lq = lane & 15, g16 = (lane >> 4) & 1;
+  int va[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+    va[dt] = (4 * lh + (lq >> 2)) * 128 + (((dt ^ ((lq >> 3) & 1)) * 4 + 2 * g16 + ((lq & 3) >> 1)) << 4) + (lq & 1) * 8;
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
+  auto read_vt = [&](const char* vtile, int dt, int i) -> uint4 {
+    const __attribute__((address_space(3))) char* vb = (const __attribute__((address_space(3))) char*)vtile + va[dt] + i * 2048;
+    const s16x4_t r0_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vb);
+    const s16x4_t r1_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vb + 1024));
+    const uint2 u0 = __builtin_bit_cast(uint2, r0_), u1 = __builtin_bit_cast(uint2, r1_);
+    return uint4{u0.x, u0.y, u1.x, u1.y};
+  };
+#else
+  auto dma_kv = [&](int, int) {};
+  auto read_vt = [&](const char*, int, int) -> uint4 { return uint4{0u, 0u, 0u, 0u}; };
+#endif
 
   const int ntiles = (S - 1 + ATT_KT - 1) / ATT_KT;  // tiles over keys 1 .. S-1
-  if (ntiles > 0) ATT_LOAD_KV(0);
+  if (ntiles > 0) dma_kv(0, 0);
 
   const float cexp = 0.125f * 1.4426950408889634f;  // softmax scale folded into exp2
   // ---- key 0 on the VALU: s0 = <q, k0> (this lane holds 32 of the 64 d of its query; the other 32 sit in lane ^ 32)
@@ -150,11 +168,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       }
   }
 
-  if (ntiles > 0) ATT_STORE_KV(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile 0 have landed
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1) < ntiles;
-    if (more) ATT_LOAD_KV(t + 1);
+    if (more) dma_kv(t + 1, (t + 1) & 1);   // the other stage: everybody left it at the barrier below
     const char* sk = smem + (t & 1) * STAGE;
     const char* sv = sk + ATT_K_BYTES;
     if (wave_active) {
@@ -167,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         const int chunk = 2 * ks + lh;
         const int koff0 = lr * 128 + ((chunk ^ ((lr >> 1) & 7)) << 4);  // rows lr and 32 + lr share (row >> 1) & 7
         const int koff1 = koff0 + 32 * 128;
-        const uint4 kf0 = *(const uint4*)(sk + koff0);
-        const uint4 kf1 = *(const uint4*)(sk + koff1);
+        // (ext-vector loads, not HIP's uint4 struct: behind a struct-typed LDS load hipcc waits vmcnt(0) for the LDS-DMA issued
+        //  at the top of the iteration -- the prefetch of tile t + 1 would be drained before tile t is multiplied)
+        const uint4 kf0 = lds_read16(sk + koff0), kf1 = lds_read16(sk + koff1);
         if (PL == 2) {
-          const uint4 kl0 = *(const uint4*)(sk + ATT_STAGE + koff0);
-          const uint4 kl1 = *(const uint4*)(sk + ATT_STAGE + koff1);
+          const uint4 kl0 = lds_read16(sk + ATT_STAGE + koff0), kl1 = lds_read16(sk + ATT_STAGE + koff1);
           s0 = T16<DT>::mfma32(kl0, qf[ks], s0);
           s1 = T16<DT>::mfma32(kl1, qf[ks], s1);
           s0 = T16<DT>::mfma32(kf0, ql[ks], s0);
@@ -232,12 +250,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       for (int i = 0; i < 4; ++i) {  // i = sub * 2 + s2: the V^T chunk pair (2 i, 2 i + 1) holds these 16 keys
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const int drow = dt * 32 + lr;
-          const int vchunk = i * 2 + lh;
-          const int voff = drow * 128 + ((vchunk ^ ((drow >> 1) & 7) ^ ((drow >> 4) & 3)) << 4);
-          const uint4 vf = *(const uint4*)(sv + voff);
+          const uint4 vf = read_vt(sv, dt, i);
           if (PL == 2) {
-            const uint4 vl = *(const uint4*)(sv + ATT_STAGE + voff);
+            const uint4 vl = read_vt(sv + ATT_STAGE, dt, i);
             o[dt] = T16<DT>::mfma32(vl, pf[i], o[dt]);
             o[dt] = T16<DT>::mfma32(vf, pl2[i], o[dt]);
           }
@@ -245,11 +260,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         }
       }
     }
-    if (more) ATT_STORE_KV((t + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t + 1 have landed
     __syncthreads();
   }
-#undef ATT_LOAD_KV
-#undef ATT_STORE_KV
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -276,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
 
 hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, int heads, Planes pl, hipStream_t stream) {
   const int BH = B * heads;
+  if ((long long)B * S * 3 * heads * ATT_D * 2 >= (1ll << 31)) return hipErrorInvalidValue;   // 32-bit buffer offsets of the LDS-DMA
   dim3 grid(((S + 127) / 128) * BH);
   if (mode == MODE_BF16)
     hipLaunchKernelGGL((attention_kernel<DT_BF16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, 0ll);

@@ -51,7 +51,10 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default=None, help="comma separated shape names")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="images (conv shapes only): 16 = what one of the two streams launches")
     args = ap.parse_args()
+    global B
+    B = args.batch
     only = set(args.only.split(",")) if args.only else None
     ITERS[0] = args.iters
     build()
