@@ -21,6 +21,7 @@ The line also carries
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -36,6 +37,19 @@ GEMM_GMAC_PER_IMAGE = {"normal": 121.487, "depth": 121.478, "dual": 179.153}  # 
 GFLOP_LARGE = {"normal": 516.43, "depth": 516.41}
 GEMM_GMAC_LARGE = {"normal": 241.855, "depth": 241.845}
 PEAK_TFLOPS = 2500.0                                           # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+
+
+def spawn_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` re-executes itself as when N > 1 and no launcher set WORLD_SIZE: one rank per
+    GPU under torch.distributed.run (the form the driver's scaling run uses; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come
+    from it).  Rendezvous on 127.0.0.1 -- the container hostname may not resolve."""
+    if port is None:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -62,13 +76,41 @@ def main():
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (functional test of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: all ranks use cuda:0 (needs --dist-backend gloo)")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="launch the N ranks, count them with one all-reduce (gloo, no GPU touched), print {n_gpus, ranks_seen} "
+                         "and exit: the CPU test of the --gpus N launch path")
     args = ap.parse_args()
 
+    # --gpus N is the number of ranks.  Under a launcher (torch.distributed.run: the driver's N > 1 form) WORLD_SIZE is set and
+    # must agree; a plain `python bench.py --gpus N` starts the N ranks itself by re-executing under torch.distributed.run.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.stdout.flush()
+        os.execv(sys.executable, spawn_command(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; the line would "
+                         f"report the wrong n_gpus -- pass --gpus {world} (or launch {args.gpus} ranks)")
+    if args.rendezvous_check:
+        import torch.distributed as dist
+        seen = 1
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks_seen": seen, "rendezvous_check": True}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path exists only as HIP kernels (no CPU fallback)")
+    if not args.share_gpu and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPUs (one rank per GPU; "
+                         "--share-gpu --dist-backend gloo is the one-GPU functional test of the N > 1 path)")
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -123,10 +165,21 @@ def main():
         eng.forward(x, out=y)
     sync_all()
     elapsed = time.perf_counter() - t0
+    # what proves that N ranks ran, each on its own GPU: an all-reduce of 1, every rank's device index and own clock
+    ranks_seen, rank_devices, per_rank = 1, [local_rank], [args.batch * args.steps / elapsed]
     if world > 1:
+        own = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        one = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        g = torch.zeros(world, 2, dtype=torch.float64, device=device)   # a gather as a sum of one-hot rows (gloo has no CUDA all_gather)
+        g[rank, 0], g[rank, 1] = float(torch.cuda.current_device()), args.batch * args.steps / own
+        dist.all_reduce(g)
+        rank_devices = [int(v) for v in g[:, 0].tolist()]
+        per_rank = [float(v) for v in g[:, 1].tolist()]
     assert torch.isfinite(y.float()).all()
 
     # ---- roofline of the dominant kernel family: HIP events around every launch, separate passes
@@ -335,6 +388,9 @@ def main():
                                    + ("(backbone vitl16_384: SURVEY.md 8f row 3, not a BASELINE.json configuration)" if large else
                                       f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])"), "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"replicas x{world} (no collective in the loop)",
+                       "ranks_seen": ranks_seen, "rank_devices": rank_devices, "dist_backend": args.dist_backend if world > 1 else None,
+                       "per_rank_images_per_s": {"min": round(min(per_rank), 2), "max": round(max(per_rank), 2)},
+                       "weight_broadcast": getattr(eng, "replication", None),
                        "schedule": "each forward = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)",
                        # A/B switches of the library that were set in this process's environment: none
                        # in a default run -- a stray one would otherwise change the kernels under the number unseen

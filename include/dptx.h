@@ -328,7 +328,8 @@ int dptx_debug_arena_checksums(dptx_handle h, void* out_dev, int32_t capacity, v
 int dptx_debug_set_launch_sums(dptx_handle h, void* dev_buf, int32_t capacity);
 /* Debug / tests: switches (per calling host thread) of the 256x256 GEMM kernel's launch form -- 1: staged epilogue instead of the
  * register-direct one, 2: one block per tile instead of the persistent tile loop, 4: the lockstep loop instead of the ping-pong
- * schedule in the two-plane 128x128 kernel.  Results do not depend on them. */
+ * schedule in the two-plane 128x128 kernel, 8: block-wide instead of wave-private epilogue staging for the launches that produce
+ * the LayerNorm row statistics (proj / fc2 / patch-embed).  Results do not depend on them. */
 int dptx_debug_set_gemm_flags(int32_t flags);
 /* NHWC conv on OCP e4m3 operands (the fp8 dtype's convolution): X8[B,H,W,Cin] and Wt8[Cout][k][k][Cin] are e4m3 bytes
  * (Cin % 128 == 0), fp32 accumulate on the block-scaled fp8 MFMA at unit scale; Y = act(out_scale * conv + bias) (+R) in

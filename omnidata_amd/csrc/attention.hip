@@ -289,7 +289,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
 
 hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, int heads, Planes pl, hipStream_t stream) {
   const int BH = B * heads;
-  if ((long long)B * S * 3 * heads * ATT_D * 2 >= (1ll << 31)) return hipErrorInvalidValue;   // 32-bit buffer offsets of the LDS-DMA
+  // 32-bit buffer offsets of the LDS-DMA: dptx_create / dptx_forward_hw reject such a batch x size with a message of their own
+  // (engine.hip attention_fits); this is the backstop
+  if ((long long)B * S * 3 * heads * ATT_D * 2 >= (1ll << 31)) return hipErrorInvalidValue;
   dim3 grid(((S + 127) / 128) * BH);
   if (mode == MODE_BF16)
     hipLaunchKernelGGL((attention_kernel<DT_BF16, 1>), grid, dim3(256), 2 * ATT_STAGE, stream, (const uint16_t*)qkv, (uint16_t*)out, S, heads, BH, 0ll);

@@ -1178,7 +1178,10 @@ int Run::forward(const void* x, void* y, void* y2) {
   // a GroupNorm behind every convolution bound them whatever the checkpoint)
   if (E->range_check() && E->d_range)
     chk(launch_nonfinite_scan(mx ? MODE_FP16 : dt, A(E->H0), (size_t)B * h2 * w2 * 128, E->d_range, st), "range.scan");
-  if (E->head_fused(conv2_x3)) {
+  // (a 2-MFMA second head conv -- dptx_set_layer_precision(..., 2) -- has no fused form: head_tail_x3_kernel always spends three
+  //  MFMAs and reads H0's lo plane, so the fused and the tapped forward would differ; it takes the three-launch tail.  ADVICE r4)
+  const bool conv2_two = mx && E->layer_mfmas(oc + "2.weight", DPTX_GROUP_HEAD) == 2;
+  if (E->head_fused(conv2_x3) && !conv2_two) {
     // x2 upsample + conv 128->32 + ReLU + conv 1x1 + ReLU in one launch (head.hip): the 37.7 MB/image up-sampled map
     // and the 32-channel map never reach memory.  Not with a 3-MFMA conv2, and not while stage taps are recorded ("h1").
     chk(launch_head_tail(conv2_x3 ? MODE_FP16X3 : (mx ? MODE_FP16 : dt), A(E->H0), E->w(oc + "2.weight"), E->f(oc + "2.bias"),
@@ -1248,6 +1251,14 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if ((long long)cfg->max_batch * max_h * max_w * 256 >= (1ll << 31)) return DPTX_E_INVALID;  // = max_batch <= 56 at 384x384
   if (cfg->streams < 0 || cfg->streams > 4) return DPTX_E_INVALID;
   if (cfg->backbone != DPTX_BACKBONE_VITB_RN50_384 && cfg->backbone != DPTX_BACKBONE_VITL16_384) return DPTX_E_INVALID;
+  {
+    // the attention kernel addresses a launch's qkv rows [B * S][3 * width] with 32-bit buffer offsets (LDS-DMA): reject a
+    // batch x size it cannot serve HERE instead of failing a forward with "launch failed at attention" (e.g.
+    // DPT-Large, 48 images of 1536 x 1536)
+    const long long S = (long long)(max_h / 16) * (max_w / 16) + 1;
+    const long long width = cfg->backbone == DPTX_BACKBONE_VITL16_384 ? 1024 : 768;
+    if ((long long)cfg->max_batch * S * 3 * width * 2 >= (1ll << 31)) return DPTX_E_INVALID;
+  }
   if (cfg->backbone == DPTX_BACKBONE_VITL16_384 && cfg->dual_task) return DPTX_E_INVALID;  // the dual-task model is the hybrid
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||

@@ -66,14 +66,23 @@ def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dt
         if dtype == "fp8" and calib_x is not None:
             eng.calibrate_fp8(calib_x)
         return eng
+    import time
     if dist.get_rank() == src:
         eng.load_state_dict(state_dict_fn())
         blob = eng.export_packed()
         torch.cuda.current_stream().synchronize()
+        dist.barrier()   # the receivers wait here for the host-side fold / pack, not inside the timed broadcast
+        t0 = time.perf_counter()
         broadcast_blob(blob, eng.packed_bytes, device, src)
     else:
+        dist.barrier()
+        t0 = time.perf_counter()
         blob = broadcast_blob(None, eng.packed_bytes, device, src)
         eng.import_packed(blob)
+    torch.cuda.synchronize(device)
+    # what the start-up exchange was (bench.py prints it): bytes, wall time on this rank, backend ("nccl" == RCCL on ROCm)
+    eng.replication = {"bytes": int(eng.packed_bytes), "ms": round(1e3 * (time.perf_counter() - t0), 3),
+                       "backend": dist.get_backend(), "world": dist.get_world_size(), "src": src}
     if dtype == "fp8":
         # every rank takes part in the (collective) decision whether scales travel: src says whether it has a calibration batch
         has = torch.tensor([1 if (dist.get_rank() == src and calib_x is not None) else 0], dtype=torch.int32, device=device)

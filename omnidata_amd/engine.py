@@ -97,14 +97,18 @@ _lib = None
 
 
 def _embedded_hash(path: str) -> str:
-    """`src=<hash>` of a built library, read by loading it (dptx_version()); "" if it cannot be loaded."""
+    """`src=<hash>` of a built library, read from the FILE's bytes (the dptx_version() literal "dptx ... src=<16 hex>").
+    Not by loading it: glibc matches an already-mapped object by name before it looks at the file and ctypes never
+    dlcloses, so a stale copy mapped here would be what a later CDLL(path) returns even after build() replaced the file
+    (the first run after any source change then died on the stale mapping)."""
+    import re
     try:
-        lib = C.CDLL(path)
-        lib.dptx_version.restype = C.c_char_p
-        v = lib.dptx_version().decode()
-        return v.rsplit("src=", 1)[-1] if "src=" in v else ""
-    except (OSError, AttributeError):
+        with open(path, "rb") as f:
+            data = f.read()
+    except OSError:
         return ""
+    m = re.search(rb"dptx [0-9.]+ \(gfx950[^)]*\) src=([0-9a-f]{16})", data)
+    return m.group(1).decode() if m else ""
 
 
 def load_library() -> C.CDLL:
@@ -129,7 +133,7 @@ def load_library() -> C.CDLL:
                     raise RuntimeError(f"{LIB_PATH} is {'stale (built from sources ' + have + ')' if have else 'missing'}; the tree "
                                        f"has {want} and {hipcc} is not available: run `python -m omnidata_amd.build` on a "
                                        "machine with ROCm. There is no CPU fallback.")
-                build()  # (a stale copy mapped by _embedded_hash stays mapped under its old inode; the new file is a new one)
+                build()  # nothing of the stale file is mapped in this process: its hash was read from the bytes
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not found: run `python -m omnidata_amd.build` "
                                "(or __graft_entry__.build()). There is no CPU fallback.")

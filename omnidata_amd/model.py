@@ -95,9 +95,12 @@ class _EngineGuards:
         eng.calibrate_fp8(x[: self._chunk()])
         self._fp8_scales = (self._values_version, eng.fp8_scales)
 
-    def _range_fallback_needed(self, eng, x: torch.Tensor) -> bool:
+    def _range_fallback_needed(self, eng, x: torch.Tensor, rerun=None) -> bool:
         """Called after a forward.  True: the engine left the fp16 range, the model has switched to bf16 planes and the
-        caller recomputes the batch."""
+        caller recomputes the batch.  `rerun()` repeats the forward of THIS batch on the same engine: the device flag is
+        sticky over up to `range_check_every` forwards, so a periodic read that finds it set cannot tell the arithmetic
+        from a NaN / Inf INPUT image in an earlier batch -- the current, finite batch is run once more on the
+        reset flag and the dtype is only left if that forward sets it again."""
         if not (self.overflow_fallback and self.engine_dtype in self._FP16_FALLBACK):
             return False
         tag = (self._values_version, self.engine_dtype)
@@ -109,9 +112,17 @@ class _EngineGuards:
         if not eng.range_overflowed(reset=True):
             self._range_checked = tag
             return False
-        if first and not bool(torch.isfinite(x).all()):
+        if not bool(torch.isfinite(x).all()):
             return False  # the input's problem, not the arithmetic's
         import warnings
+        if not first and rerun is not None:
+            rerun()
+            if not eng.range_overflowed(reset=True):
+                self._range_checked = tag
+                warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} saw non-finite activations in one of the previous "
+                              f"{n_since - 1} forwards, but not on this (finite) batch run again: most likely a NaN / Inf input "
+                              f"image in an earlier batch; keeping the dtype.  Results of those forwards may be non-finite.")
+                return False
         safe = self._FP16_FALLBACK[self.engine_dtype]
         warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} produced non-finite activations -- a tensor exceeds the fp16 "
                       f"range (65504) with these weights; switching this model to dtype={safe!r} (bf16 planes: fp32's range) and "
@@ -230,13 +241,13 @@ class DPTDepthModel(_EngineGuards, BaseModel):
         eng = self._get_engine(x.device)
         step = self._chunk()
         self._ensure_fp8(eng, x[:step])
-        if B <= step:
-            y = eng.forward(x)
-        else:
-            y = torch.empty(B, self.num_channels, H, W, dtype=_io_dtype(x), device=x.device)
+        y = torch.empty(B, self.num_channels, H, W, dtype=_io_dtype(x), device=x.device)
+
+        def run():
             for i in range(0, B, step):
                 eng.forward(x[i:i + step], out=y[i:i + step])
-        if self._range_fallback_needed(eng, x):
+        run()
+        if self._range_fallback_needed(eng, x, run):
             return self.forward(x)  # on the bf16-plane engine
         return y.squeeze(dim=1)  # dpt_depth.py:106-107
 
@@ -328,9 +339,11 @@ class DPTDualTaskModel(_EngineGuards, nn.Module):
         self._ensure_fp8(eng, x[:step])
         yn = torch.empty(B, 3, H, W, dtype=_io_dtype(x), device=x.device)
         yd = torch.empty(B, 1, H, W, dtype=_io_dtype(x), device=x.device)
-        for i in range(0, B, step):
-            eng.forward_dual(x[i:i + step], out_normal=yn[i:i + step], out_depth=yd[i:i + step])
-        if self._range_fallback_needed(eng, x):
+        def run():
+            for i in range(0, B, step):
+                eng.forward_dual(x[i:i + step], out_normal=yn[i:i + step], out_depth=yd[i:i + step])
+        run()
+        if self._range_fallback_needed(eng, x, run):
             return self.forward(x)  # on the bf16-plane engine
         return yn, yd.squeeze(dim=1)
 

@@ -82,3 +82,40 @@ def test_shard_range_properties():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bench(args, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    env["PYTHONPATH"] = ROOT
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
+                          cwd=ROOT, timeout=300)
+
+
+def test_bench_gpus_n_starts_n_ranks_in_the_plain_python_form():
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must itself start two ranks.  --rendezvous-check
+    stops after the ranks have counted themselves with one all-reduce, before anything touches a GPU."""
+    import json
+    r = _bench(["--gpus", "2", "--rendezvous-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"n_gpus": 2, "ranks_seen": 2, "rendezvous_check": True}
+    r = _bench(["--gpus", "1", "--rendezvous-check"])
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rendezvous-check"], capture_output=True,
+                       text=True, env=env, cwd=ROOT, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_spawn_command_is_the_drivers_launch_form():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.spawn_command(8, ["--gpus", "8", "--steps", "5"], port=29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")

@@ -73,3 +73,18 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["scaling"] == "weak"
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_bench_plain_python_gpus_2_spawns_two_ranks():
+    """the plain `python bench.py --gpus 2` form (no launcher) starts the two ranks itself; the line proves it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--profile-steps", "1"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["global_batch"] == 8 and len(cfg["rank_devices"]) == 2
+    assert cfg["weight_broadcast"]["bytes"] > 200e6 and cfg["weight_broadcast"]["ms"] > 0 and cfg["weight_broadcast"]["backend"] == "gloo"
+    assert cfg["per_rank_images_per_s"]["min"] > 0

@@ -316,6 +316,25 @@ def test_fp16_overflow_fallback_control_flow(monkeypatch):
         for _ in range(16):
             model(x)
     assert model.engine_dtype == "bf16x3"
+    # the flag is sticky -- set once by an EARLIER batch (e.g. a NaN input image) and found by the periodic read, it
+    # must not switch the dtype: the current finite batch is run again on the reset flag, comes back clean, the dtype stays
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=False)
+    model(x)
+    engines[0].flag = True
+    with pytest.warns(UserWarning, match="earlier batch"):
+        for _ in range(16):
+            model(x)
+    assert model.engine_dtype == "mixed" and len(engines) == 1
+    assert engines[0].calls[-4:] == [("forward", 3), ("range", True), ("forward", 3), ("range", True)]
+    # ... and a non-finite CURRENT input never switches it either, first forward or periodic read
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=False)
+    model(x)
+    engines[0].overflow = True
+    bad_now = x.clone()
+    bad_now[1, 2, 3, 4] = float("nan")
+    for _ in range(16):
+        model(bad_now.as_subclass(_FakeCudaTensor))
+    assert model.engine_dtype == "mixed" and len(engines) == 1
     # the dual-task model has the same guard
     model, engines = _stubbed_model(monkeypatch, "mixed", overflow=True, cls=DPTDualTaskModel)
     with pytest.warns(UserWarning, match="fp16 range"):
@@ -372,3 +391,35 @@ def test_fp8_calibration_is_explicit_or_announced_and_survives_engine_rebuilds(m
         model2.calibrate(x)
         model2(x)
     assert e2.calls[:2] == [("calibrate", 3), ("forward", 3)]
+
+
+def test_stale_library_is_rebuilt_and_loaded_in_the_same_process(built_lib, tmp_path, monkeypatch):
+    """load_library() used to dlopen the stale libdptx.so to read its hash; glibc then returned that mapping for the
+    rebuilt file of the same name and the first run after any source change died.  A LOADABLE stale library (same soname-less
+    path, old `src=`) must be replaced and the new one loaded by this very call."""
+    import shutil
+    from omnidata_amd import build as build_mod
+    from omnidata_amd import engine as eng_mod
+    stale_c = tmp_path / "stale.c"
+    stale_c.write_text('const char* dptx_version(void) { return "dptx 0.3.0 (gfx950) src=0123456789abcdef"; }\n')
+    lib = tmp_path / "libdptx.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(lib), str(stale_c)], check=True)
+    assert eng_mod._embedded_hash(str(lib)) == "0123456789abcdef"
+    calls = []
+
+    def fake_build(*a, **k):   # what build() does for the real path: link to a temporary name, rename into place
+        calls.append(1)
+        tmp = str(lib) + ".tmp"
+        shutil.copy(built_lib, tmp)
+        os.replace(tmp, str(lib))
+        return str(lib)
+
+    monkeypatch.setattr(eng_mod, "LIB_PATH", str(lib))
+    monkeypatch.setattr(eng_mod, "_lib", None)
+    monkeypatch.setattr(build_mod, "build", fake_build)
+    monkeypatch.delenv("DPTX_LIB", raising=False)
+    monkeypatch.delenv("DPTX_SKIP_HASH_CHECK", raising=False)
+    got = eng_mod.load_library()
+    assert calls == [1]
+    assert got.dptx_version().decode().endswith("src=" + build_mod.source_hash(os.environ.get("DPTX_CXXFLAGS", "").split()))
+    assert hasattr(got, "dptx_range_status")   # a symbol the stale stub does not have
