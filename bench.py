@@ -39,15 +39,20 @@ GEMM_GMAC_LARGE = {"normal": 241.855, "depth": 241.845}
 PEAK_TFLOPS = 2500.0                                           # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def spawn_command(n_gpus, argv, port=None):
     """The command `python bench.py --gpus N ...` re-executes itself as when N > 1 and no launcher set WORLD_SIZE: one rank per
     GPU under torch.distributed.run (the form the driver's scaling run uses; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come
     from it).  Rendezvous on 127.0.0.1 -- the container hostname may not resolve."""
     if port is None:
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
+        port = free_port()
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
@@ -76,6 +81,10 @@ def main():
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (functional test of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: all ranks use cuda:0 (needs --dist-backend gloo)")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="N = 1 only: initialise the process group anyway (backend --dist-backend, nccl = RCCL) and run the N > 1 "
+                         "start-up path -- packed-weight export, broadcast, import on a second handle, byte comparison -- plus one "
+                         "all-reduce, on this one GPU; the line's config.weight_broadcast records it")
     ap.add_argument("--rendezvous-check", action="store_true",
                     help="launch the N ranks, count them with one all-reduce (gloo, no GPU touched), print {n_gpus, ranks_seen} "
                          "and exit: the CPU test of the --gpus N launch path")
@@ -116,8 +125,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.dist_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -141,7 +154,11 @@ def main():
     C = 1 if args.task == "depth" else 3
     make_sd = (lambda: random_dual_state_dict(0)) if dual else (lambda: random_state_dict(0, C, backbone=args.backbone))
     eng = build_replicated_engine(make_sd, C, args.batch, args.dtype, local_rank, dual=dual, x3_groups=args.x3_groups,
-                                  backbone=args.backbone)
+                                  backbone=args.backbone, selftest=args.dist_selftest and world == 1)
+    if args.dist_selftest and world == 1:   # one collective besides the broadcast
+        one = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(one)
+        assert int(one.item()) == 1
     io_dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.io]
     x = synthetic_input(1000 + rank, args.batch, "normal" if dual else args.task).to(device).to(io_dt)
     y = torch.empty(args.batch, C, 384, 384, dtype=io_dt, device=device)
@@ -388,7 +405,7 @@ def main():
                                    + ("(backbone vitl16_384: SURVEY.md 8f row 3, not a BASELINE.json configuration)" if large else
                                       f"(BASELINE.json configs[{ {'normal': 1, 'depth': 2, 'dual': 4}[args.task] }])"), "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"replicas x{world} (no collective in the loop)",
-                       "ranks_seen": ranks_seen, "rank_devices": rank_devices, "dist_backend": args.dist_backend if world > 1 else None,
+                       "ranks_seen": ranks_seen, "rank_devices": rank_devices, "dist_backend": args.dist_backend if (world > 1 or args.dist_selftest) else None,
                        "per_rank_images_per_s": {"min": round(min(per_rank), 2), "max": round(max(per_rank), 2)},
                        "weight_broadcast": getattr(eng, "replication", None),
                        "schedule": "each forward = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)",
@@ -400,7 +417,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "also": also, "kernel_breakdown": breakdown,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.dist_selftest:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1613,6 +1613,10 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
           return hipGetLastError();
         }
       }
+      // DPTX_STATS_WP=0: block-wide staging for the row-statistics producers (round 4's form; = debug flag 8, A/B runs)
+      static int stats_wp = -1;
+      if (stats_wp < 0) { const char* e = getenv("DPTX_STATS_WP"); stats_wp = e ? atoi(e) : 1; }
+      if (!stats_wp) q.debug_flags |= 8;
       if (p.a_relu) go(gemm_pp_kernel<DT, true, PLE>);
       else go(gemm_pp_kernel<DT, false, PLE>);
       return hipGetLastError();

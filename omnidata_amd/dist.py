@@ -48,7 +48,8 @@ def broadcast_fp8_calibration(eng, x: Optional[torch.Tensor], device: torch.devi
 
 
 def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dtype: str, device_index: int, src: int = 0,
-                            dual: bool = False, x3_groups=0, backbone: str = "vitb_rn50_384", calib_x=None):
+                            dual: bool = False, x3_groups=0, backbone: str = "vitb_rn50_384", calib_x=None,
+                            selftest: bool = False):
     """Every rank gets an Engine with identical packed weights; only `src` runs the host-side
     fold/pack (state_dict_fn() is called on `src` only).
 
@@ -56,17 +57,43 @@ def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dt
     representative batch on `src`'s device; other ranks may pass None) is measured on `src` and the scales travel with
     the weights (one more 512-byte broadcast).  Without `calib_x` the engine stays uncalibrated: calibrate one rank and
     call broadcast_fp8_calibration, or every rank would calibrate on its own shard and the replicas would diverge
-    (the model warns when it has to calibrate implicitly)."""
+    (the model warns when it has to calibrate implicitly).
+
+    selftest (bench.py --dist-selftest): with ONE rank and an initialised process group the exchange still runs -- export,
+    broadcast through the backend (RCCL when "nccl": communicator set-up and one collective on the device blob), and the
+    RECEIVER's half on a second handle (import_packed) whose re-exported blob must equal the sender's byte for byte.  That is
+    the N > 1 start-up path executed end to end on a one-GPU box; `eng.replication["selftest"]` records it."""
     from .engine import Engine
     eng = Engine(num_channels=num_channels, max_batch=max_batch, dtype=dtype, device_id=device_index, dual=dual,
                  x3_groups=x3_groups, backbone=backbone)
     device = torch.device("cuda", device_index)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not selftest):
         eng.load_state_dict(state_dict_fn())
         if dtype == "fp8" and calib_x is not None:
             eng.calibrate_fp8(calib_x)
         return eng
     import time
+    if dist.get_world_size() == 1:   # selftest: sender and receiver are this rank
+        eng.load_state_dict(state_dict_fn())
+        blob = eng.export_packed()
+        torch.cuda.current_stream().synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        got = broadcast_blob(blob, eng.packed_bytes, device, src)
+        torch.cuda.synchronize(device)
+        ms = 1e3 * (time.perf_counter() - t0)
+        rx = Engine(num_channels=num_channels, max_batch=1, dtype=dtype, device_id=device_index, dual=dual, x3_groups=x3_groups,
+                    backbone=backbone)
+        rx.import_packed(got)
+        same = bool(torch.equal(rx.export_packed(), blob))
+        rx.close()
+        if not same:
+            raise RuntimeError("dist selftest: the blob re-exported by the receiving handle differs from the sender's")
+        eng.replication = {"bytes": int(eng.packed_bytes), "ms": round(ms, 3), "backend": dist.get_backend(), "world": 1, "src": src,
+                           "selftest": "one rank: export -> broadcast -> import on a second handle -> re-export == sent blob"}
+        if dtype == "fp8" and calib_x is not None:
+            eng.calibrate_fp8(calib_x)
+        return eng
     if dist.get_rank() == src:
         eng.load_state_dict(state_dict_fn())
         blob = eng.export_packed()

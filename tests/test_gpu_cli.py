@@ -88,3 +88,18 @@ def test_bench_plain_python_gpus_2_spawns_two_ranks():
     assert line["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["global_batch"] == 8 and len(cfg["rank_devices"]) == 2
     assert cfg["weight_broadcast"]["bytes"] > 200e6 and cfg["weight_broadcast"]["ms"] > 0 and cfg["weight_broadcast"]["backend"] == "gloo"
     assert cfg["per_rank_images_per_s"]["min"] > 0
+
+
+def test_bench_dist_selftest_runs_the_rccl_start_up_path_on_one_gpu():
+    """the `nccl` (= RCCL) branch of the N > 1 path had never executed anywhere (the one-GPU functional test is
+    gloo: RCCL refuses two ranks on one device).  --dist-selftest runs it with ONE rank: communicator set-up, the broadcast of
+    the packed weights on the device, the receiver's import on a second handle (bytes compared), one all-reduce."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--dist-selftest", "--no-cpu-baseline", "--no-also", "--parity-dtype", "none", "--profile-steps", "1"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    wb = line["config"]["weight_broadcast"]
+    assert line["n_gpus"] == 1 and wb["backend"] == "nccl" and wb["bytes"] > 200e6 and "selftest" in wb
