@@ -77,6 +77,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary measurements (depth, dual-task bf16 / fp8) "
                                                             "that the default N = 1 normal-head run appends under 'also'")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight per GPU in the timed loop (omnidata_amd/pipeline.py ForwardPipeline: that many handles, "
+                         "one stream each, one shared copy of the weights; every step is still one forward of one batch of --batch "
+                         "images).  1 = round 4's schedule: one forward at a time, its two halves on two streams.  The line "
+                         "carries the other schedule's number from the same run under config.schedule_ab")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (functional test of the N>1 path)")
@@ -174,14 +179,54 @@ def main():
     if args.dtype == "fp8":  # per-tensor activation scales of the e4m3 copies: rank 0 measures them on its batch
         from omnidata_amd.dist import broadcast_fp8_calibration
         broadcast_fp8_calibration(eng, x, device)
-    for _ in range(args.warmup):
-        eng.forward(x, out=y)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.forward(x, out=y)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+
+    # the timed loop: K steps, each ONE forward of one batch; with --inflight n > 1 consecutive steps go to n handles on n
+    # streams (one copy of the weights) and overlap -- every step is enqueued inside the timed region and complete at its end
+    from omnidata_amd.pipeline import ForwardPipeline
+
+    def timed(e_, inflight, steps, warmup, x_, y_, dual_=False, y2_=None):
+        """seconds for `steps` forwards of x_ on engine e_ (weights loaded) with `inflight` forwards in flight, all finite?"""
+        pipe = ForwardPipeline.from_engine(e_, depth=inflight) if inflight > 1 else None
+        ys_ = [y_] + [torch.empty_like(y_) for _ in range(inflight - 1)]
+        y2s_ = ([y2_] + [torch.empty_like(y2_) for _ in range(inflight - 1)]) if dual_ else None
+
+        def one(i):
+            k = i % inflight
+            if pipe is None:
+                if dual_:
+                    e_.forward_dual(x_, out_normal=y_, out_depth=y2_)
+                else:
+                    type(e_).forward(e_, x_, out=y_)
+            elif dual_:
+                pipe.submit(x_, out=ys_[k], out_depth=y2s_[k])
+            else:
+                pipe.submit(x_, out=ys_[k])
+        for i in range(max(warmup, inflight)):
+            one(i)
+        sync_all()
+        t_ = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        sync_all()
+        dt_ = time.perf_counter() - t_
+        ok_ = all(bool(torch.isfinite(t.float()).all()) for t in ys_)
+        if pipe is not None:
+            pipe.close()
+        return dt_, ok_
+
+    # The other schedule first (rank 0, N = 1), the headline last: what --inflight buys on THIS box in THIS process.  (First, so
+    # that the engine's two internal streams exist before the pipeline's: measured the other way round -- lease r5l3 -- the
+    # one-forward-at-a-time loop ran at 1993 instead of ~2600 images/s, i.e. its two half-batch streams no longer overlapped;
+    # HIP maps streams onto a small number of hardware queues in creation order.)
+    schedule_ab = None
+    if rank == 0 and world == 1:
+        other = 1 if args.inflight > 1 else 2
+        dt_o, _ = timed(eng, other, args.steps, args.warmup, x, y, dual, y2 if dual else None)
+        schedule_ab = {"inflight": other, "value": round(args.batch * args.steps / dt_o, 2), "unit": "images/s",
+                       "ms_per_step": round(1e3 * dt_o / args.steps, 3),
+                       "note": "same process, same weights, measured right before the headline loop"}
+    elapsed, finite = timed(eng, args.inflight, args.steps, args.warmup, x, y, dual, y2 if dual else None)
+    assert finite
     # what proves that N ranks ran, each on its own GPU: an all-reduce of 1, every rank's device index and own clock
     ranks_seen, rank_devices, per_rank = 1, [local_rank], [args.batch * args.steps / elapsed]
     if world > 1:
@@ -197,8 +242,6 @@ def main():
         dist.all_reduce(g)
         rank_devices = [int(v) for v in g[:, 0].tolist()]
         per_rank = [float(v) for v in g[:, 1].tolist()]
-    assert torch.isfinite(y.float()).all()
-
     # ---- roofline of the dominant kernel family: HIP events around every launch, separate passes
     roofline = None
     breakdown = None
@@ -304,34 +347,22 @@ def main():
                         x3_groups=args.parity_x3_groups, backbone=args.backbone)
             pe.load_state_dict(sd)
             pm = max_abs(pe, oracle_ref)
-            fwd = (lambda: pe.forward_dual(x, out_normal=y, out_depth=y2)) if dual else (lambda: pe.forward(x, out=y))
-            for _ in range(args.warmup):
-                fwd()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                fwd()
-            torch.cuda.synchronize()
-            pdt = time.perf_counter() - t1
+            pdt1, _ = timed(pe, 1 if args.inflight > 1 else 2, args.steps, args.warmup, x, y, dual, y2 if dual else None)
+            pdt, _ = timed(pe, args.inflight, args.steps, args.warmup, x, y, dual, y2 if dual else None)   # the headline's schedule
             parity["parity_mode"] = {"dtype": args.parity_dtype,
                                      "x3_groups": args.parity_x3_groups or "default (all layer groups but the ViT blocks)",
                                      "value": round(args.batch * args.steps / pdt, 2), "unit": "images/s",
                                      "ms_per_step": round(1e3 * pdt / args.steps, 3), "max_abs": round(pm, 6),
-                                     "meets_1e-3": bool(pm < 1e-3)}
+                                     "meets_1e-3": bool(pm < 1e-3), "inflight": args.inflight,
+                                     "schedule_ab": {"inflight": 1 if args.inflight > 1 else 2,
+                                                     "value": round(args.batch * args.steps / pdt1, 2)}}
             if args.parity_dtype == "mixed" and not args.parity_x3_groups:
                 # the measured option outside the default table (include/dptx.h dptx_set_layer_precision): the first head
                 # convolution on two MFMAs -- weights exact, input rounded once
                 for k in (("scratch.output_conv.0.weight", "depth.scratch.output_conv.0.weight") if dual else ("scratch.output_conv.0.weight",)):
                     pe.set_layer_precision(k, 2)
                 pm2 = max_abs(pe, oracle_ref)
-                for _ in range(args.warmup):
-                    fwd()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    fwd()
-                torch.cuda.synchronize()
-                pdt = time.perf_counter() - t1
+                pdt, _ = timed(pe, args.inflight, args.steps, args.warmup, x, y, dual, y2 if dual else None)
                 parity["parity_mode_head0_2mfma"] = {"dtype": "mixed", "layer_precision": {"scratch.output_conv.0.weight": 2},
                                                      "value": round(args.batch * args.steps / pdt, 2), "unit": "images/s",
                                                      "ms_per_step": round(1e3 * pdt / args.steps, 3), "max_abs": round(pm2, 6),
@@ -358,16 +389,8 @@ def main():
             yb = torch.empty(args.batch, 1, 384, 384, dtype=io_dt, device=device)
             if dtype2.startswith("fp8"):
                 e2.calibrate_fp8(x2)
-            f2 = (lambda: e2.forward_dual(x2, out_normal=ya, out_depth=yb)) if d2 else (lambda: e2.forward(x2, out=ya))
             n2 = max(4, min(args.steps, 10))
-            for _ in range(3):
-                f2()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(n2):
-                f2()
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
+            dt2, _ = timed(e2, args.inflight, n2, 3, x2, ya, d2, yb if d2 else None)    # the headline's schedule
             max_abs2 = None
             if dtype2 == "mixed" and not args.no_cpu_baseline:   # the dual-task parity mode against the oracle (2 images, both heads)
                 from oracle.dpt_oracle import dpt_forward_dual, oracle_threads
@@ -376,7 +399,7 @@ def main():
                 rn, rd = dpt_forward_dual(random_dual_state_dict(0), x2[:2].float().cpu())
                 max_abs2 = round(max(float((ya[:2].float().cpu() - rn).abs().max()), float((yb[:2, 0].float().cpu() - rd).abs().max())), 6)
             also.append({"workload": f"DPT-Hybrid-384 {task2}, batch {args.batch}, {dtype2}, 1xMI355X (BASELINE.json configs[{cfg_i}])",
-                         "task": task2, "dtype": dtype2, "value": round(args.batch * n2 / dt2, 2), "unit": "images/s",
+                         "task": task2, "dtype": dtype2, "value": round(args.batch * n2 / dt2, 2), "unit": "images/s", "inflight": args.inflight,
                          "steps": n2, "ms_per_step": round(1e3 * dt2 / n2, 3),
                          "e2e_tflops_algorithmic": round(args.batch * n2 / dt2 * GFLOP_PER_IMAGE[task2] / 1e3, 1),
                          "max_abs_vs_oracle": max_abs2,
@@ -408,7 +431,11 @@ def main():
                        "ranks_seen": ranks_seen, "rank_devices": rank_devices, "dist_backend": args.dist_backend if (world > 1 or args.dist_selftest) else None,
                        "per_rank_images_per_s": {"min": round(min(per_rank), 2), "max": round(max(per_rank), 2)},
                        "weight_broadcast": getattr(eng, "replication", None),
-                       "schedule": "each forward = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)",
+                       "schedule": (f"{args.inflight} forwards of {args.batch} images in flight per GPU: {args.inflight} handles x 1 stream, one "
+                                    f"shared copy of the weights (omnidata_amd/pipeline.py); batch latency ~ {args.inflight} x ms_per_step"
+                                    if args.inflight > 1 else
+                                    "one forward at a time = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)"),
+                       "inflight": args.inflight, "schedule_ab": schedule_ab,
                        # A/B switches of the library that were set in this process's environment: none
                        # in a default run -- a stray one would otherwise change the kernels under the number unseen
                        "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DPTX_")}},

@@ -146,6 +146,15 @@ int dptx_export_packed_host(dptx_handle h, void* dst_host, size_t bytes);
  * (RCCL) broadcasts it over xGMI, the other ranks import it instead of packing themselves. */
 int dptx_export_packed_device(dptx_handle h, void* dst_dev, size_t bytes, void* stream);
 int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, void* stream);
+/* Round 5: `dst` uses `src`'s packed weights IN PLACE (no copy): both handles must live on the same device and have been created
+ * with configurations that pack the same blob (same layout header, same size); `src` must have its weights on the device and
+ * must outlive `dst` (or `dst` must load / import weights of its own first -- either un-shares it).  A handle is not
+ * re-entrant, so several forwards in flight on one GPU need several handles (each with its own activation arena, on its own
+ * stream): this lets them read ONE copy of the 244 MB of weights out of L2 / Infinity Cache instead of one copy each
+ * (omnidata_amd/pipeline.py ForwardPipeline: two batch-32 forwards in flight, +8 % images/s over the two-halves-of-one-forward
+ * schedule -- the ResNetV2 stages of one forward then run under the MFMA-bound ViT / decoder launches of the other).
+ * The packed blob is read-only during forwards. */
+int dptx_share_packed(dptx_handle dst, dptx_handle src);
 
 /* Bytes of device memory held by the handle (packed weights + activation arena). */
 size_t dptx_workspace_bytes(dptx_handle h);
@@ -328,8 +337,7 @@ int dptx_debug_arena_checksums(dptx_handle h, void* out_dev, int32_t capacity, v
 int dptx_debug_set_launch_sums(dptx_handle h, void* dev_buf, int32_t capacity);
 /* Debug / tests: switches (per calling host thread) of the 256x256 GEMM kernel's launch form -- 1: staged epilogue instead of the
  * register-direct one, 2: one block per tile instead of the persistent tile loop, 4: the lockstep loop instead of the ping-pong
- * schedule in the two-plane 128x128 kernel, 8: block-wide instead of wave-private epilogue staging for the launches that produce
- * the LayerNorm row statistics (proj / fc2 / patch-embed).  Results do not depend on them. */
+ * schedule in the two-plane 128x128 kernel.  Results do not depend on them. */
 int dptx_debug_set_gemm_flags(int32_t flags);
 /* NHWC conv on OCP e4m3 operands (the fp8 dtype's convolution): X8[B,H,W,Cin] and Wt8[Cout][k][k][Cin] are e4m3 bytes
  * (Cin % 128 == 0), fp32 accumulate on the block-scaled fp8 MFMA at unit scale; Y = act(out_scale * conv + bias) (+R) in

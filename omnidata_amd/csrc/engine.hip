@@ -331,6 +331,7 @@ struct dptx_engine {
   bool finalized = false;  // host blob valid
   bool device_ready = false;
   char* d_blob = nullptr;
+  bool blob_shared = false;   // d_blob belongs to another handle (dptx_share_packed): not freed, never written
   char* d_arena = nullptr;
   size_t arena_bytes = 0;
   std::string err;
@@ -1349,7 +1350,7 @@ void dptx_destroy(dptx_handle h) {
   if (!h) return;
   if (h->cfg.device_id >= 0) {
     DeviceGuard guard(h->cfg.device_id);
-    if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->d_blob && !h->blob_shared) (void)hipFree(h->d_blob);
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
     if (h->d_amax) (void)hipFree(h->d_amax);
@@ -1381,10 +1382,12 @@ int dptx_load_tensor(dptx_handle h, const char* ref_key, const float* host_fp32,
   return DPTX_OK;
 }
 
-static int ensure_device_memory(dptx_handle h) {
+// own_blob: the caller is about to WRITE the blob (finalize / import): a handle that shares another's gets one of its own first
+static int ensure_device_memory(dptx_handle h, bool own_blob = true) {
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
-  if (!h->d_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, h->packed_bytes));
+  if (own_blob && h->blob_shared) { h->d_blob = nullptr; h->blob_shared = false; h->device_ready = false; }
+  if (!h->d_blob && own_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, h->packed_bytes));
   if (!h->d_arena) HIPCHK(h, hipMalloc((void**)&h->d_arena, h->arena_bytes));
   if (!h->d_range) {
     HIPCHK(h, hipMalloc((void**)&h->d_range, 256));
@@ -1455,6 +1458,26 @@ int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, 
   }
   HIPCHK(h, hipMemcpyAsync(h->d_blob, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   h->device_ready = true;
+  return DPTX_OK;
+}
+
+int dptx_share_packed(dptx_handle dst, dptx_handle src) {
+  if (!dst || !src || dst == src) return DPTX_E_INVALID;
+  if (dst->cfg.device_id < 0 || src->cfg.device_id < 0) return dst->fail(DPTX_E_NODEVICE, "host-only handle");
+  if (dst->cfg.device_id != src->cfg.device_id) return dst->fail(DPTX_E_INVALID, "dptx_share_packed: the handles live on different devices");
+  if (!src->device_ready || !src->d_blob) return dst->fail(DPTX_E_INVALID, "dptx_share_packed: the source handle has no weights on the device");
+  if (src->blob_shared) return dst->fail(DPTX_E_INVALID, "dptx_share_packed: share from the handle that owns the weights");
+  const BlobHeader a = dst->blob_header(), b = src->blob_header();
+  if (dst->packed_bytes != src->packed_bytes || memcmp(&a, &b, sizeof a) != 0)
+    return dst->fail(DPTX_E_INVALID, "dptx_share_packed: the handles pack different blobs (dtype / backbone / channels / dual task / fold)");
+  DeviceGuard guard(dst->cfg.device_id);
+  HIPCHK(dst, guard.err);
+  if (dst->d_blob && !dst->blob_shared) HIPCHK(dst, hipFree(dst->d_blob));
+  dst->d_blob = src->d_blob;
+  dst->blob_shared = true;
+  const int r = ensure_device_memory(dst, false);   // arena + range flag
+  if (r != DPTX_OK) return r;
+  dst->device_ready = true;
   return DPTX_OK;
 }
 

@@ -235,7 +235,7 @@ __device__ __forceinline__ void mma_tile(const char* sa, const char* sb, int a_l
 template <int DT, int BM, int BN, int TM, int TN, int PL = 1, int NT = 256, int SLABS = 1, bool ILV = false, bool WP = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                          int tid, f32x16_t (&acc)[TM][TN], int row_pitch = 0, bool dma_in_flight = false,
-                                         int trace_row = -1, const char* lds_ln = nullptr, float2* stats_part = nullptr) {
+                                         int trace_row = -1, const char* lds_ln = nullptr) {
   // lds_ln (persistent gemm_pp_kernel): the (sum, sum of squares) records of the tile's BM rows, 64 bytes per tile row,
   // already in LDS (DMA'd at the start of the tile's k-loop; rows >= M read as zeros and are masked below)
   // dma_in_flight (persistent gemm_pp_kernel): the caller has LDS-DMA of its next tile outstanding; the epilogue waits for
@@ -243,17 +243,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   // would wait for the tile to reach memory)
   // row_pitch != 0 (gemm_halo_kernel): the tile is 8 image rows x 32 pixels -- tile row R is GEMM row
   // m0 + (R >> 5) * row_pitch + (R & 31)
-  // stats_part (WP with row_stats; round 5): LDS table [BM rows][4 wave columns] of (sum, sum of squares) over a wave's 64
-  // columns of a row.  A 128-column record spans two waves, which is why the producers of the LayerNorm statistics (proj /
-  // fc2 / patch-embed) kept the block-wide staging -- 28-31 k cycles per tile against 12.6 k for the wave-private form
-  // (profiles/r03_tile_trace.txt).  Here every wave reduces its own eight 8-column chunks with the first three levels of the
-  // block-wide form's shuffle tree (lane ^ 1, ^ 2, ^ 4: the same operand pairs), parks the partial in the table, and after ONE
-  // block barrier thread (row, block) adds lower + upper wave -- the tree's fourth level -- and writes the record: the same
-  // additions in the same order, bit-identical records (tests/test_gpu_ops.py test_stats_epilogue_forms_agree_bit_for_bit).
   static_assert(SLABS == 1 || SLABS == TM, "one slab, or one per MFMA row tile");
   static_assert(!ILV || (SLABS == TM && TM == 4 && TN == 2 && BM == 256 && BN == 256), "interleaved mapping: the phased kernel");
   static_assert(!WP || (SLABS == TM && TN == 2 && !ILV), "wave-private staging: one 32 x 64 block per wave and slab");
-  static_assert(!WP || BN == 256, "stats_part: four wave columns");
   constexpr int CT_PITCH = WP ? 72 : BN + 4;  // floats (WP: 4 rows apart = 32 banks apart)
   constexpr int CT_ROWS = WP ? 32 : BM / SLABS;
   constexpr int NCH = WP ? 8 : BN / 8;       // 8-column chunks per staged row
@@ -529,17 +521,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
             float sm = 0.f, sq = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sm += v[e]; sq = fmaf(v[e], v[e], sq); }
-            if constexpr (WP) {
-              // this wave's eight chunks: levels 1..3 of the tree; the partial waits in LDS for the neighbouring wave's (below)
 #pragma unroll
-              for (int o = 1; o < 8; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
-              if (cn == 0) stats_part[(wm * (TM * 32) + s * 32 + row) * 4 + wn] = make_float2(sm, sq);
-            } else {
-#pragma unroll
-              for (int o = 1; o < 16; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }  // fixed order
-              if (ok[it] && (cn & 15) == 0)
-                ((float2*)p.row_stats)[(long long)crow_[it] * p.stats_nblk + ((n0 + cn * 8) >> 7)] = make_float2(sm, sq);
-            }
+            for (int o = 1; o < 16; o <<= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }  // fixed order
+            if (ok[it] && (cn & 15) == 0)
+              ((float2*)p.row_stats)[(long long)crow_[it] * p.stats_nblk + ((n0 + cn * 8) >> 7)] = make_float2(sm, sq);
           }
           if (ok[it]) {
             if (p.C16 != nullptr) store8f<DT, 1>((uint16_t*)p.C16 + coff[it], 0, v);
@@ -581,25 +566,6 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, char* smem, int m0
   else if (has1 && !p.r1_fp32 && !has2 && !p.bias_per_img) body(I1{}, I0{}, I0{}, I0{});  // RCU conv2
   else if (has1 && !p.r1_fp32 && has2 && !p.r2_fp32 && !p.bias_per_img) body(I1{}, I1{}, I0{}, I0{});  // RCU conv2 + path
   else body(IX{}, IX{}, IX{}, I0{});  // patch-embed, readout
-  if constexpr (WP) {
-    if (p.row_stats != nullptr) {
-      // level 4 of the tree: record (row, 128-column block) = lower wave's partial + upper wave's, one per thread
-      __syncthreads();
-      static_assert(NT == 2 * BM, "one record per thread");
-      const int r = tid >> 1, blk = tid & 1;
-      const int m = m0 + r;
-      if (m < p.M) {
-        int img = 0, pp = m;
-        if (remap) {
-          img = m / c_rpi;
-          pp = m - img * c_rpi;
-        }
-        const long long crow = (long long)img * p.c_img_rows + p.c_row_off + pp;
-        const float2 a = stats_part[r * 4 + 2 * blk], b = stats_part[r * 4 + 2 * blk + 1];
-        ((float2*)p.row_stats)[crow * p.stats_nblk + ((n0 >> 7) + blk)] = make_float2(a.x + b.x, a.y + b.y);
-      }
-    }
-  }
 #undef DPTX_ESTAMP
 }
 
@@ -1179,12 +1145,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
         (void)trow; (void)wp_ok;
         epilogue_direct<DT>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, more,
                             p.ln_stats != nullptr ? smem + LN_LDS : nullptr);
-      } else if (wp_ok && (p.row_stats == nullptr || (p.ln_stats == nullptr && !(p.debug_flags & 8))))
-        // (a statistics producer -- proj / fc2 / patch-embed -- is never a consumer: the records' LDS region holds its partials)
+      } else if (wp_ok && p.row_stats == nullptr)
         epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS, false, true>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow,
-                                                                  p.ln_stats != nullptr ? smem + LN_LDS : nullptr,
-                                                                  (float2*)(smem + LN_LDS));
-      else  // debug flag 8 (A/B runs, the bit-identity test): the producer side of the LayerNorm fold with block-wide staging
+                                                                  p.ln_stats != nullptr ? smem + LN_LDS : nullptr);
+      else  // the producer side of the LayerNorm fold reduces 128 columns of a row: block-wide staging
         epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow);
     }
     DPTX_TSTAMP(3);
@@ -1613,10 +1577,6 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
           return hipGetLastError();
         }
       }
-      // DPTX_STATS_WP=0: block-wide staging for the row-statistics producers (round 4's form; = debug flag 8, A/B runs)
-      static int stats_wp = -1;
-      if (stats_wp < 0) { const char* e = getenv("DPTX_STATS_WP"); stats_wp = e ? atoi(e) : 1; }
-      if (!stats_wp) q.debug_flags |= 8;
       if (p.a_relu) go(gemm_pp_kernel<DT, true, PLE>);
       else go(gemm_pp_kernel<DT, false, PLE>);
       return hipGetLastError();

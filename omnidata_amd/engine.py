@@ -57,6 +57,7 @@ ABI = [
     ("dptx_set_layer_precision", C.c_int, [_vp, C.c_char_p, _i32]),
     ("dptx_calibrate_fp8", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_fp8_get_calibration", C.c_int, [_vp, _f32p, _f32p, _i32]),
+    ("dptx_share_packed", C.c_int, [_vp, _vp]),
     ("dptx_fp8_set_calibration", C.c_int, [_vp, _f32p, _i32]),
     ("dptx_range_status", C.c_int, [_vp, C.POINTER(C.c_int32), _i32, _vp]),
     ("dptx_tap", C.c_int, [_vp, C.c_char_p, _vp, _sz, _i64p]),
@@ -241,6 +242,12 @@ class Engine:
         t = torch.empty(self.packed_bytes, dtype=torch.uint8, device=f"cuda:{self.cfg.device_id}")
         self._check(self.lib.dptx_export_packed_device(self.h, t.data_ptr(), t.numel(), _stream(t.device)), "export_packed_device")
         return t
+
+    def share_weights_from(self, owner: "Engine"):
+        """This handle reads `owner`'s packed weights in place (include/dptx.h dptx_share_packed): no second copy on the device.
+        `owner` is kept alive by this object; loading / importing weights of its own un-shares it."""
+        self._check(self.lib.dptx_share_packed(self.h, owner.h), "share_packed")
+        self._weights_owner = owner
 
     def import_packed(self, blob: torch.Tensor):
         assert blob.is_cuda and blob.dtype == torch.uint8 and blob.is_contiguous()

@@ -197,6 +197,41 @@ class DPTDepthModel(_EngineGuards, BaseModel):
         self._values_version += 1
         return r
 
+    @torch.no_grad()
+    def forward_pipelined(self, batches, depth: int = 2):
+        """Throughput form of ``model(x)`` for a STREAM of batches (each [B,3,H,W], B <= max_batch, 384x384 or any one size the
+        engine is planned for): a generator of the results in order, with ``depth`` whole-batch forwards in flight on the GPU
+        (omnidata_amd/pipeline.py: +8 % images/s at B = 32 over calling the model batch by batch; each result is bit-identical
+        to ``model(x)``).  The fp16 range guard of ``forward`` does not run per batch here: the flags of the pipeline's handles
+        are read once at the end and reported with a warning (no automatic dtype switch)."""
+        from .pipeline import ForwardPipeline
+        pipe = None
+        try:
+            pending = []
+            for x in batches:
+                if not x.is_cuda:
+                    raise RuntimeError("omnidata_amd.DPTDepthModel runs only on an AMD GPU (HIP); there is no CPU fallback")
+                if pipe is None:
+                    eng = self._get_engine(x.device)
+                    self._ensure_fp8(eng, x[: self._chunk()])
+                    pipe = ForwardPipeline.from_engine(eng, depth=depth)
+                pending.append(pipe.submit(x))
+                if len(pending) >= depth:
+                    yield pending.pop(0).wait().squeeze(dim=1)
+            while pending:
+                yield pending.pop(0).wait().squeeze(dim=1)
+            if pipe is not None and self.overflow_fallback and self.engine_dtype in self._FP16_FALLBACK:
+                pipe.synchronize()
+                if any(e.range_overflowed(reset=True) for e in pipe.engines):
+                    import warnings
+                    warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} produced non-finite activations in forward_pipelined "
+                                  f"(fp16 range exceeded, or a non-finite input); results may be affected -- model(x) falls back to "
+                                  f"bf16 planes by itself, the pipelined form does not.")
+        finally:
+            if pipe is not None:
+                pipe.synchronize()
+                pipe.close()
+
     def _apply(self, fn, *a, **kw):
         r = super()._apply(fn, *a, **kw)
         self._weights_version += 1

@@ -307,13 +307,10 @@ def test_gemm_launch_forms_agree_bit_for_bit():
             model.load_state_dict(random_state_dict(0, 3))
             model.to(DEV)
             outs = []
-            for flags in (0, 1, 3, 8):
+            for flags in (0, 1, 3):
                 lib.dptx_debug_set_gemm_flags(flags)
                 outs.append(model(x).clone())
             assert torch.equal(outs[0], outs[1]), dtype   # direct == staged
             assert torch.equal(outs[1], outs[2]), dtype   # persistent == one block per tile
-            # round 5: the row-statistics producers (proj / fc2 / patch-embed) stage per wave and combine two waves' partial
-            # sums through LDS; flag 8 = the block-wide staging with the 16-lane shuffle tree.  Same additions, same order.
-            assert torch.equal(outs[0], outs[3]), dtype
     finally:
         lib.dptx_debug_set_gemm_flags(0)

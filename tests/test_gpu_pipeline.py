@@ -1,0 +1,95 @@
+"""Round 5: several forwards in flight on one GPU (omnidata_amd/pipeline.py, include/dptx.h dptx_share_packed).  The pipeline's
+handles share ONE copy of the packed weights and free-run on their own streams; every result must be the single-handle
+forward's, bit for bit -- same kernels, same arithmetic, only the interleaving on the chip differs.  pytest -m gpu."""
+import pytest
+import torch
+
+from omnidata_amd.engine import Engine
+from omnidata_amd.model import DPTDepthModel
+from omnidata_amd.pipeline import ForwardPipeline
+from omnidata_amd.weights import random_dual_state_dict, random_state_dict, synthetic_input
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "mixed"])
+def test_pipelined_forwards_equal_the_single_handle_forward_bitwise(dtype):
+    sd = random_state_dict(0, 3)
+    ref_eng = Engine(num_channels=3, max_batch=8, dtype=dtype, device_id=0)
+    ref_eng.load_state_dict(sd)
+    batches = [synthetic_input(20 + i, b, "normal").to(DEV) for i, b in enumerate((8, 8, 3, 8, 1, 8, 5))]   # ragged sizes too
+    refs = [ref_eng.forward(x).clone() for x in batches]
+    torch.cuda.synchronize()
+    for depth in (2, 3):
+        pipe = ForwardPipeline(depth=depth, num_channels=3, max_batch=8, dtype=dtype, device_id=0)
+        pipe.load_state_dict(sd)
+        for rep in range(3):   # the slots are re-used: a forward must not see its predecessor's arena content
+            outs = list(pipe.map(batches))
+            torch.cuda.synchronize()
+            assert len(outs) == len(refs)
+            for i, (o, r) in enumerate(zip(outs, refs)):
+                assert torch.equal(o, r), (dtype, depth, rep, i)
+        # explicit tickets into caller buffers, waited for in reverse order
+        ys = [torch.empty_like(r) for r in refs]
+        tickets = [pipe.submit(x, out=y) for x, y in zip(batches, ys)]
+        for t in reversed(tickets):
+            t.wait()
+        torch.cuda.synchronize()
+        assert all(torch.equal(y, r) for y, r in zip(ys, refs)) and all(t.done() for t in tickets)
+        pipe.close()
+    ref_eng.close()
+
+
+def test_shared_weights_are_one_copy_and_unshare_on_load():
+    lib = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    lib.load_state_dict(random_state_dict(0, 3))
+    other = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    other.share_weights_from(lib)
+    x = synthetic_input(5, 2, "normal").to(DEV)
+    y0 = lib.forward(x).clone()
+    assert torch.equal(other.forward(x), y0)
+    # the sharer re-exports the owner's bytes
+    assert torch.equal(other.export_packed(), lib.export_packed())
+    # weights of its own un-share it: the owner is untouched
+    other.load_state_dict(random_state_dict(1, 3))
+    y1 = other.forward(x).clone()
+    assert not torch.equal(y1, y0) and torch.equal(lib.forward(x), y0)
+    # a handle that packs another blob is refused, with a message
+    wrong = Engine(num_channels=1, max_batch=2, dtype="bf16", device_id=0)
+    with pytest.raises(RuntimeError, match="share_packed"):
+        wrong.share_weights_from(lib)
+    wrong2 = Engine(num_channels=3, max_batch=2, dtype="fp16", device_id=0)
+    with pytest.raises(RuntimeError, match="share_packed"):
+        wrong2.share_weights_from(lib)
+    empty = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    late = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    with pytest.raises(RuntimeError, match="share_packed"):
+        late.share_weights_from(empty)    # no weights on the device yet
+    for e in (other, wrong, wrong2, late, empty, lib):
+        e.close()
+
+
+def test_dual_task_pipeline_and_model_generator():
+    sd = random_dual_state_dict(0)
+    eng = Engine(num_channels=3, max_batch=4, dtype="bf16", device_id=0, dual=True)
+    eng.load_state_dict(sd)
+    xs = [synthetic_input(40 + i, 4, "normal").to(DEV) for i in range(4)]
+    refs = [tuple(t.clone() for t in eng.forward_dual(x)) for x in xs]
+    pipe = ForwardPipeline.from_engine(eng, depth=2)
+    outs = list(pipe.map(xs))
+    torch.cuda.synchronize()
+    for (n, d), (rn, rd) in zip(outs, refs):
+        assert torch.equal(n, rn) and torch.equal(d, rd)
+    pipe.close()
+    eng.close()
+    # the drop-in model's throughput form: a generator over batches, each result == model(x)
+    model = DPTDepthModel(num_channels=1, dtype="mixed", max_batch=4)
+    model.load_state_dict(random_state_dict(2, 1))
+    model.to(DEV)
+    ds = [synthetic_input(60 + i, 4, "depth").to(DEV) for i in range(5)]
+    want = [model(x).clone() for x in ds]
+    got = list(model.forward_pipelined(ds, depth=2))
+    torch.cuda.synchronize()
+    assert len(got) == 5 and all(g.shape == (4, 384, 384) for g in got)
+    assert all(torch.equal(g, w) for g, w in zip(got, want))
