@@ -82,6 +82,7 @@ def main():
                          "one stream each, one shared copy of the weights; every step is still one forward of one batch of --batch "
                          "images).  1 = round 4's schedule: one forward at a time, its two halves on two streams.  The line "
                          "carries the other schedule's number from the same run under config.schedule_ab")
+    ap.add_argument("--no-schedule-ab", action="store_true", help="skip the other schedule's loop (rocprofv3 passes: one schedule per trace)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (functional test of the N>1 path)")
@@ -219,7 +220,7 @@ def main():
     # one-forward-at-a-time loop ran at 1993 instead of ~2600 images/s, i.e. its two half-batch streams no longer overlapped;
     # HIP maps streams onto a small number of hardware queues in creation order.)
     schedule_ab = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_schedule_ab:
         other = 1 if args.inflight > 1 else 2
         dt_o, _ = timed(eng, other, args.steps, args.warmup, x, y, dual, y2 if dual else None)
         schedule_ab = {"inflight": other, "value": round(args.batch * args.steps / dt_o, 2), "unit": "images/s",
@@ -267,7 +268,7 @@ def main():
         # figure is the committed rocprofv3 measurement of this very command (profiles/README.md), scaled
         # from its batch to this one; null when no measurement is committed for the dtype.
         traffic = None
-        for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json", "r04_pmc_traffic.json"):  # newest committed round wins
+        for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json", "r04_pmc_traffic.json", "r05_pmc_traffic.json"):  # newest committed round wins
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and args.dtype == "bf16" and not large:
                 tj = json.load(open(tpath))

@@ -1382,6 +1382,7 @@ int dptx_load_tensor(dptx_handle h, const char* ref_key, const float* host_fp32,
   return DPTX_OK;
 }
 
+static int ensure_sub_streams(dptx_handle h);
 // own_blob: the caller is about to WRITE the blob (finalize / import): a handle that shares another's gets one of its own first
 static int ensure_device_memory(dptx_handle h, bool own_blob = true) {
   DeviceGuard guard(h->cfg.device_id);
@@ -1393,7 +1394,7 @@ static int ensure_device_memory(dptx_handle h, bool own_blob = true) {
     HIPCHK(h, hipMalloc((void**)&h->d_range, 256));
     HIPCHK(h, hipMemset(h->d_range, 0, 256));
   }
-  return DPTX_OK;
+  return ensure_sub_streams(h);
 }
 
 int dptx_finalize_weights(dptx_handle h) {
@@ -1500,6 +1501,20 @@ int dptx_enable_taps(dptx_handle h, int on) {
 // joined to the caller's stream with events.  Images are independent and every kernel is batch-invariant bit for bit, so
 // both schedules return the same bits; the second one lets the MFMA-bound launches of one half overlap the HBM-bound
 // launches and the tails of the other.
+// The internal streams of the sub-batch schedule.  Created when the handle gets its device memory (round 5), not at the first
+// forward: HIP maps streams onto hardware queues as they are created, and a handle whose streams came into being AFTER a
+// process had created many others (torch's stream pool) was measured with its two half-batch runs no longer overlapping --
+// 1990 instead of 2600 images/s (profiles/r05_experiments.md).
+static int ensure_sub_streams(dptx_handle h) {
+  if (h->ev_fork || h->n_streams < 2) return DPTX_OK;
+  for (int r = 0; r < h->n_streams && r < dptx_engine::MAX_STREAMS; ++r) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[r], hipEventDisableTiming));
+  }
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  return DPTX_OK;
+}
+
 static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, int batch, int height, int width,
                        hipStream_t stream) {
   const int C = h->cfg.num_channels;
@@ -1530,12 +1545,9 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
   }
   const int nr = batch < h->n_streams ? batch : h->n_streams;  // sub-batches: the first (batch % nr) get one image more
   gemm_set_cu_share(share_env > 0.f ? share_env : 1.0f / (float)nr, share_small_env > 0.f ? share_small_env : 1.0f);
-  if (!h->ev_fork) {
-    for (int r = 0; r < dptx_engine::MAX_STREAMS; ++r) {
-      HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));
-      HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[r], hipEventDisableTiming));
-    }
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  {
+    const int rs = ensure_sub_streams(h);
+    if (rs != DPTX_OK) return rs;
   }
   HIPCHK(h, hipEventRecord(h->ev_fork, stream));
   const size_t px = (size_t)height * width;
