@@ -1507,8 +1507,17 @@ int dptx_enable_taps(dptx_handle h, int on) {
 // 1990 instead of 2600 images/s (profiles/r05_experiments.md).
 static int ensure_sub_streams(dptx_handle h) {
   if (h->ev_fork || h->n_streams < 2) return DPTX_OK;
+  // One stream PRIORITY per sub-batch stream, cycling through the device's range: the runtime keeps a separate pool of
+  // hardware queues per priority, so streams of different priorities can never be mapped onto the same queue -- which is what
+  // happens to same-priority streams once a process holds more streams than queues (GPU_MAX_HW_QUEUES, 4), and then the two
+  // half-batch runs execute one after the other (1974 instead of 2600 images/s, lease r5l4).  The priorities only order the
+  // dispatch of ready work between the halves; both halves are needed before the forward is complete.
+  int pri_least = 0, pri_greatest = 0;
+  HIPCHK(h, hipDeviceGetStreamPriorityRange(&pri_least, &pri_greatest));   // numerically: least >= greatest
+  const int levels = pri_least - pri_greatest + 1;
   for (int r = 0; r < h->n_streams && r < dptx_engine::MAX_STREAMS; ++r) {
-    HIPCHK(h, hipStreamCreateWithFlags(&h->sub_stream[r], hipStreamNonBlocking));
+    const int pri = levels > 1 ? pri_least - (r % levels) : pri_least;
+    HIPCHK(h, hipStreamCreateWithPriority(&h->sub_stream[r], hipStreamNonBlocking, pri));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[r], hipEventDisableTiming));
   }
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -1533,7 +1542,11 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
   // whatever path leaves this function (HIPCHK returns included), the thread's tile-selection state is back at "whole chip"
   struct ShareReset { ~ShareReset() { gemm_set_cu_share(1.0f); } } share_reset;
   if (!split) {
-    gemm_set_cu_share(1.0f);
+    // DPTX_CU_SHARE_WHOLE (A/B runs): tile selection of a whole-batch run that shares the GPU with another handle's forward
+    // (omnidata_amd/pipeline.py) -- measured neutral, profiles/r05_experiments.md
+    static float whole_env = -1.f;
+    if (whole_env < 0.f) { const char* t = getenv("DPTX_CU_SHARE_WHOLE"); whole_env = t ? (float)atof(t) : 0.f; }
+    gemm_set_cu_share(whole_env > 0.f ? whole_env : 1.0f);
     Run run{h, batch, stream, h->cfg.dtype, height, width, io};
     const int rc = run.forward(x, y, y2);
     h->launches = run.launches;

@@ -67,7 +67,17 @@ class ForwardPipeline:
         self.depth = int(depth)
         self.engines: List[Engine] = [Engine(**engine_kwargs) for _ in range(self.depth)]
         self.device = torch.device("cuda", self.engines[0].cfg.device_id)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.depth)]
+        # One stream PRIORITY per slot, cycling through the device's range.  The runtime keeps a separate pool of hardware
+        # queues per priority; same-priority streams share queues once a process holds more streams than queues (torch's own
+        # pool is 32 per priority), and two slots that land on one queue run one after the other -- measured: 2488 instead of
+        # 2820 images/s, depending on nothing but the order in which unrelated streams had been created
+        # (profiles/r05_experiments.md).  Different priorities cannot collide.
+        try:
+            least, greatest = torch.cuda.Stream.priority_range()  # numerically least >= greatest (e.g. 0, -1)
+        except Exception:
+            least, greatest = 0, -1
+        levels = list(range(least, greatest - 1, -1)) or [0]
+        self.streams = [torch.cuda.Stream(device=self.device, priority=levels[i % len(levels)]) for i in range(self.depth)]
         self._next = 0
         self.dual = bool(engine_kwargs.get("dual", False))
 
