@@ -390,7 +390,7 @@ def main():
             yb = torch.empty(args.batch, 1, 384, 384, dtype=io_dt, device=device)
             if dtype2.startswith("fp8"):
                 e2.calibrate_fp8(x2)
-            n2 = max(4, min(args.steps, 10))
+            n2 = max(4, min(args.steps, 20))
             dt2, _ = timed(e2, args.inflight, n2, 3, x2, ya, d2, yb if d2 else None)    # the headline's schedule
             max_abs2 = None
             if dtype2 == "mixed" and not args.no_cpu_baseline:   # the dual-task parity mode against the oracle (2 images, both heads)
