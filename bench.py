@@ -104,6 +104,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE thing: rank 0's JSON line.  Libraries print there too (RCCL's version banner goes to the C stdout and
+    # is flushed at exit, i.e. AFTER a Python print -- found in this round's evidence run), so file descriptor 1 is pointed at
+    # stderr for the whole run and the line is written to the saved descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; the line would "
                          f"report the wrong n_gpus -- pass --gpus {world} (or launch {args.gpus} ranks)")
@@ -119,7 +128,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"n_gpus": world, "ranks_seen": seen, "rendezvous_check": True}), flush=True)
+            emit({"n_gpus": world, "ranks_seen": seen, "rendezvous_check": True})
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path exists only as HIP kernels (no CPU fallback)")
@@ -444,10 +453,11 @@ def main():
             "e2e_tflops_algorithmic": round(e2e_tflops, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "also": also, "kernel_breakdown": breakdown,
         }
-        print(json.dumps(line), flush=True)
     if world > 1 or args.dist_selftest:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        emit(line)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ timeout 300 python bench.py --dtype mixed --steps 5 --warmup 2 --no-cpu-baseline
 DPTX_STREAMS=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-also --parity-dtype none --inflight 1 --no-schedule-ab > $O/bench_1stream.log 2>&1; tail -1 $O/bench_1stream.log | cut -c1-120
 timeout 400 python bench.py --backbone vitl16_384 --task depth --steps 8 --warmup 3 --no-also > $O/bench_vitl16.log 2>&1; tail -1 $O/bench_vitl16.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('vitl16', d['value'], d['roofline']['frac'], d['config']['schedule_ab'], d['parity']['parity_mode']['value'], d['parity']['parity_mode']['max_abs'])"
 timeout 300 python tools/gemm_bench.py --only cal.4096,cal.8192,vit.qkv,vit.proj,vit.fc1,vit.fc2,rcu@96,rcu@48,head.0,l2_rn,l3_rn,s2.c1,s2.c2,s2.c3 --iters 30 > $O/gemm_shapes.txt 2>&1; grep TF/s $O/gemm_shapes.txt | tail -16
-timeout 200 python bench.py --gpus 1 --steps 3 --warmup 1 --dist-selftest --no-cpu-baseline --no-also --parity-dtype none --no-schedule-ab --profile-steps 1 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('dist selftest:', d['config']['weight_broadcast'])" | tee $O/dist_selftest.txt
+timeout 200 python bench.py --gpus 1 --steps 3 --warmup 1 --dist-selftest --no-cpu-baseline --no-also --parity-dtype none --no-schedule-ab --profile-steps 1 2>/dev/null | grep "^{" | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('dist selftest:', d['config']['weight_broadcast'])" | tee $O/dist_selftest.txt
 cd /tmp
 export DPTX_STREAMS=1   # kernel-level passes: one launch per layer over the whole batch (the bench's per-launch figures)
 B="python $R/bench.py --no-cpu-baseline --no-also --parity-dtype none --profile-steps 1 --inflight 1 --no-schedule-ab"
