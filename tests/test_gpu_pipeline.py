@@ -93,3 +93,25 @@ def test_dual_task_pipeline_and_model_generator():
     torch.cuda.synchronize()
     assert len(got) == 5 and all(g.shape == (4, 384, 384) for g in got)
     assert all(torch.equal(g, w) for g, w in zip(got, want))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "mixed"])
+def test_pipelined_stress_b32_bit_identical(dtype):
+    """Two batch-32 forwards in flight put ViT block 0 of one forward next to the stem / first ResNetV2 stage of the other ALL the
+    time -- the co-residency that exposed round 3's packed-fma fault.  120 pipelined forwards of four
+    different batches, every result compared with the forward computed alone."""
+    sd = random_state_dict(0, 3)
+    eng = Engine(num_channels=3, max_batch=32, dtype=dtype, device_id=0, streams=1)
+    eng.load_state_dict(sd)
+    xs = [synthetic_input(70 + i, 32, "normal").to(DEV) for i in range(4)]
+    refs = [eng.forward(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    pipe = ForwardPipeline.from_engine(eng, depth=2)
+    bad = 0
+    for rnd in range(10):
+        outs = list(pipe.map([xs[i % 4] for i in range(12)]))
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(o, refs[i % 4]) else 1 for i, o in enumerate(outs))
+    pipe.close()
+    eng.close()
+    assert bad == 0, f"{bad} of 120 pipelined forwards differ from the forward computed alone"

@@ -423,3 +423,19 @@ def test_stale_library_is_rebuilt_and_loaded_in_the_same_process(built_lib, tmp_
     assert calls == [1]
     assert got.dptx_version().decode().endswith("src=" + build_mod.source_hash(os.environ.get("DPTX_CXXFLAGS", "").split()))
     assert hasattr(got, "dptx_range_status")   # a symbol the stale stub does not have
+
+
+def test_pipeline_has_no_cpu_fallback_and_ticket_api():
+    """omnidata_amd/pipeline.py (round 5): importable without a GPU, but a pipeline needs device handles -- no CPU path."""
+    from omnidata_amd import pipeline
+    assert {"submit", "map", "forward", "load_state_dict", "import_packed", "from_engine", "close"} <= set(dir(pipeline.ForwardPipeline))
+    with pytest.raises(ValueError):
+        pipeline.ForwardPipeline(depth=2, device_id=None)
+    with pytest.raises(ValueError):
+        pipeline.ForwardPipeline(depth=0)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            pipeline.ForwardPipeline(depth=2, num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+        model = DPTDepthModel(num_channels=3, dtype="bf16", max_batch=2)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            list(model.forward_pipelined([torch.rand(1, 3, 384, 384)]))
