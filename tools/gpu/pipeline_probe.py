@@ -3,7 +3,7 @@ on two streams and joins them before the next forward may start, so the latency-
 other, never the MFMA-bound ViT / decoder launches.  Here H engine handles (each with its own arena and internal stream count)
 free-run K forwards each on H torch streams with no synchronisation between steps: aggregate images/s.
 
-  python tools/gpu/r5/pipeline_probe.py [--dtype bf16] [--steps 20]
+  python tools/gpu/pipeline_probe.py [--dtype bf16] [--steps 20]
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from omnidata_amd.engine import Engine  # noqa: E402
 from omnidata_amd.weights import random_state_dict, synthetic_input  # noqa: E402
 
