@@ -147,8 +147,10 @@ int dptx_export_packed_host(dptx_handle h, void* dst_host, size_t bytes);
 int dptx_export_packed_device(dptx_handle h, void* dst_dev, size_t bytes, void* stream);
 int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, void* stream);
 /* Round 5: `dst` uses `src`'s packed weights IN PLACE (no copy): both handles must live on the same device and have been created
- * with configurations that pack the same blob (same layout header, same size); `src` must have its weights on the device and
- * must outlive `dst` (or `dst` must load / import weights of its own first -- either un-shares it).  A handle is not
+ * with configurations that pack the same blob (same layout header, same size); `src` must have its weights on the device.  The
+ * allocation is reference-counted: the handles may be destroyed in any order (the last one frees it), and a handle that loads or
+ * imports weights while others read its blob writes a fresh allocation instead -- sharing is a snapshot, never an alias of a
+ * blob that changes under a reader.  A handle is not
  * re-entrant, so several forwards in flight on one GPU need several handles (each with its own activation arena, on its own
  * stream): this lets them read ONE copy of the 244 MB of weights out of L2 / Infinity Cache instead of one copy each
  * (omnidata_amd/pipeline.py ForwardPipeline: two batch-32 forwards in flight, +8 % images/s over the two-halves-of-one-forward

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -331,7 +332,10 @@ struct dptx_engine {
   bool finalized = false;  // host blob valid
   bool device_ready = false;
   char* d_blob = nullptr;
-  bool blob_shared = false;   // d_blob belongs to another handle (dptx_share_packed): not freed, never written
+  // The packed blob's allocation is reference-counted: dptx_share_packed hands a second handle the same memory, and whichever
+  // handle is destroyed LAST frees it -- destroying the handle that loaded the weights while others still read them is legal.
+  std::shared_ptr<void> blob_hold;
+  bool blob_shared = false;   // this handle did not load the blob it reads (dptx_share_packed): it never writes it
   char* d_arena = nullptr;
   size_t arena_bytes = 0;
   std::string err;
@@ -1350,7 +1354,7 @@ void dptx_destroy(dptx_handle h) {
   if (!h) return;
   if (h->cfg.device_id >= 0) {
     DeviceGuard guard(h->cfg.device_id);
-    if (h->d_blob && !h->blob_shared) (void)hipFree(h->d_blob);
+    h->blob_hold.reset();   // frees the packed blob if this was its last user (hipFree in the deleter)
     if (h->d_arena) (void)hipFree(h->d_arena);
     if (h->d_tok_taps) (void)hipFree(h->d_tok_taps);
     if (h->d_amax) (void)hipFree(h->d_amax);
@@ -1387,8 +1391,23 @@ static int ensure_sub_streams(dptx_handle h);
 static int ensure_device_memory(dptx_handle h, bool own_blob = true) {
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
-  if (own_blob && h->blob_shared) { h->d_blob = nullptr; h->blob_shared = false; h->device_ready = false; }
-  if (!h->d_blob && own_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, h->packed_bytes));
+  // a handle about to WRITE a blob that others read too (it shares somebody's, or somebody shares its own) takes a fresh one
+  if (own_blob && h->d_blob && (h->blob_shared || h->blob_hold.use_count() > 1)) {
+    h->blob_hold.reset();
+    h->d_blob = nullptr;
+    h->blob_shared = false;
+    h->device_ready = false;
+  }
+  if (!h->d_blob && own_blob) {
+    void* p = nullptr;
+    HIPCHK(h, hipMalloc(&p, h->packed_bytes));
+    const int dev = h->cfg.device_id;
+    h->blob_hold = std::shared_ptr<void>(p, [dev](void* q) {
+      DeviceGuard g(dev);
+      (void)hipFree(q);
+    });
+    h->d_blob = (char*)p;
+  }
   if (!h->d_arena) HIPCHK(h, hipMalloc((void**)&h->d_arena, h->arena_bytes));
   if (!h->d_range) {
     HIPCHK(h, hipMalloc((void**)&h->d_range, 256));
@@ -1467,13 +1486,12 @@ int dptx_share_packed(dptx_handle dst, dptx_handle src) {
   if (dst->cfg.device_id < 0 || src->cfg.device_id < 0) return dst->fail(DPTX_E_NODEVICE, "host-only handle");
   if (dst->cfg.device_id != src->cfg.device_id) return dst->fail(DPTX_E_INVALID, "dptx_share_packed: the handles live on different devices");
   if (!src->device_ready || !src->d_blob) return dst->fail(DPTX_E_INVALID, "dptx_share_packed: the source handle has no weights on the device");
-  if (src->blob_shared) return dst->fail(DPTX_E_INVALID, "dptx_share_packed: share from the handle that owns the weights");
   const BlobHeader a = dst->blob_header(), b = src->blob_header();
   if (dst->packed_bytes != src->packed_bytes || memcmp(&a, &b, sizeof a) != 0)
     return dst->fail(DPTX_E_INVALID, "dptx_share_packed: the handles pack different blobs (dtype / backbone / channels / dual task / fold)");
   DeviceGuard guard(dst->cfg.device_id);
   HIPCHK(dst, guard.err);
-  if (dst->d_blob && !dst->blob_shared) HIPCHK(dst, hipFree(dst->d_blob));
+  dst->blob_hold = src->blob_hold;   // (a blob of dst's own is released here if nobody else holds it)
   dst->d_blob = src->d_blob;
   dst->blob_shared = true;
   const int r = ensure_device_memory(dst, false);   // arena + range flag

@@ -245,7 +245,8 @@ class Engine:
 
     def share_weights_from(self, owner: "Engine"):
         """This handle reads `owner`'s packed weights in place (include/dptx.h dptx_share_packed): no second copy on the device.
-        `owner` is kept alive by this object; loading / importing weights of its own un-shares it."""
+        The allocation is reference-counted on the C side (handles may be closed in any order); loading / importing weights
+        of its own un-shares this handle, and `owner` reloading its weights leaves this handle on the blob it shared."""
         self._check(self.lib.dptx_share_packed(self.h, owner.h), "share_packed")
         self._weights_owner = owner
 

@@ -66,7 +66,19 @@ def test_shared_weights_are_one_copy_and_unshare_on_load():
     late = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
     with pytest.raises(RuntimeError, match="share_packed"):
         late.share_weights_from(empty)    # no weights on the device yet
-    for e in (other, wrong, wrong2, late, empty, lib):
+    # the allocation is reference-counted: the handle that loaded the weights may go first, and reloading weights into a handle
+    # whose blob others read gives IT a fresh allocation (the readers keep their snapshot)
+    third = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    third.share_weights_from(lib)
+    lib.load_state_dict(random_state_dict(1, 3))          # lib now computes y1; third still reads the old blob
+    assert torch.equal(lib.forward(x), y1) and torch.equal(third.forward(x), y0)
+    fourth = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    fourth.share_weights_from(third)                        # sharing from a sharer is sharing the same allocation
+    lib.close()
+    third.close()
+    torch.cuda.synchronize()
+    assert torch.equal(fourth.forward(x), y0)
+    for e in (other, wrong, wrong2, late, empty, fourth):
         e.close()
 
 
