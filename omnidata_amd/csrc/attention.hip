@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
 
 hipError_t launch_attention(int mode, const void* qkv, void* out, int B, int S, int heads, Planes pl, hipStream_t stream) {
   const int BH = B * heads;
-  // 32-bit buffer offsets of the LDS-DMA: dptx_create / dptx_forward_hw reject such a batch x size with a message of their own
-  // (engine.hip attention_fits); this is the backstop
+  // 32-bit buffer offsets of the LDS-DMA.  Through the engine this cannot fire: dptx_create bounds max_batch * max_h * max_w * 256
+  // below 2^31, which is stricter for both backbones (engine.hip dptx_create); it guards the op-level entry point (dptx_op_attention)
   if ((long long)B * S * 3 * heads * ATT_D * 2 >= (1ll << 31)) return hipErrorInvalidValue;
   dim3 grid(((S + 127) / 128) * BH);
   if (mode == MODE_BF16)

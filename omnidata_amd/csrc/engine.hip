@@ -1256,14 +1256,9 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if ((long long)cfg->max_batch * max_h * max_w * 256 >= (1ll << 31)) return DPTX_E_INVALID;  // = max_batch <= 56 at 384x384
   if (cfg->streams < 0 || cfg->streams > 4) return DPTX_E_INVALID;
   if (cfg->backbone != DPTX_BACKBONE_VITB_RN50_384 && cfg->backbone != DPTX_BACKBONE_VITL16_384) return DPTX_E_INVALID;
-  {
-    // the attention kernel addresses a launch's qkv rows [B * S][3 * width] with 32-bit buffer offsets (LDS-DMA): reject a
-    // batch x size it cannot serve HERE instead of failing a forward with "launch failed at attention" (e.g.
-    // DPT-Large, 48 images of 1536 x 1536)
-    const long long S = (long long)(max_h / 16) * (max_w / 16) + 1;
-    const long long width = cfg->backbone == DPTX_BACKBONE_VITL16_384 ? 1024 : 768;
-    if ((long long)cfg->max_batch * S * 3 * width * 2 >= (1ll << 31)) return DPTX_E_INVALID;
-  }
+  // (the attention kernel's 32-bit LDS-DMA offsets over its qkv rows [B * S][3 * width] need B * S * 3 * width * 2 < 2^31: with
+  //  S = h * w / 256 + 1 and width <= 1024 that is implied by the activation bound above for both backbones, so there is no
+  //  separate check here; attention.hip launch_attention keeps the backstop.  ADVICE r5)
   if (cfg->backbone == DPTX_BACKBONE_VITL16_384 && cfg->dual_task) return DPTX_E_INVALID;  // the dual-task model is the hybrid
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
@@ -1456,12 +1451,12 @@ int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, 
   if (!h || !src_dev) return DPTX_E_INVALID;
   if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "host-only handle");
   if (bytes != h->packed_bytes) return h->fail(DPTX_E_INVALID, "packed blob size mismatch (different config/build?)");
-  int r = ensure_device_memory(h);
-  if (r != DPTX_OK) return r;
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
   {
-    // the blob's layout tag must be the one this handle packs itself (dtype, backbone, LayerNorm fold, weight-std form ...)
+    // the blob's layout tag must be the one this handle packs itself (dtype, backbone, LayerNorm fold, weight-std form ...).
+    // Checked BEFORE the handle's state is touched: a rejected import leaves a working handle -- its own blob,
+    // or the one it shares -- exactly as it was
     BlobHeader got;
     HIPCHK(h, hipMemcpyAsync(&got, src_dev, sizeof got, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
@@ -1476,6 +1471,8 @@ int dptx_import_packed_device(dptx_handle h, const void* src_dev, size_t bytes, 
       return h->fail(DPTX_E_INVALID, msg);
     }
   }
+  const int r = ensure_device_memory(h);   // un-shares / allocates: only now that the source is known to be importable
+  if (r != DPTX_OK) return r;
   HIPCHK(h, hipMemcpyAsync(h->d_blob, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   h->device_ready = true;
   return DPTX_OK;

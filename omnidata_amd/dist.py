@@ -20,6 +20,16 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _barrier(device_index: int):
+    """dist.barrier() on THIS rank's device.  With the nccl (= RCCL) backend a bare barrier() makes torch guess the device as
+    rank % n_gpus unless init_process_group got device_id; a caller whose device_index differs from that guess would create a
+    communicator on the wrong GPU, which torch warns can hang."""
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[int(device_index)])
+    else:
+        _barrier(device_index)
+
+
 def broadcast_blob(blob: Optional[torch.Tensor], nbytes: int, device: torch.device, src: int = 0) -> torch.Tensor:
     """Broadcasts a uint8 blob of known size from `src`; other ranks pass blob=None."""
     if dist.get_rank() == src:
@@ -77,7 +87,7 @@ def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dt
         eng.load_state_dict(state_dict_fn())
         blob = eng.export_packed()
         torch.cuda.current_stream().synchronize()
-        dist.barrier()
+        _barrier(device_index)
         t0 = time.perf_counter()
         got = broadcast_blob(blob, eng.packed_bytes, device, src)
         torch.cuda.synchronize(device)
@@ -98,11 +108,11 @@ def build_replicated_engine(state_dict_fn, num_channels: int, max_batch: int, dt
         eng.load_state_dict(state_dict_fn())
         blob = eng.export_packed()
         torch.cuda.current_stream().synchronize()
-        dist.barrier()   # the receivers wait here for the host-side fold / pack, not inside the timed broadcast
+        _barrier(device_index)   # the receivers wait here for the host-side fold / pack, not inside the timed broadcast
         t0 = time.perf_counter()
         broadcast_blob(blob, eng.packed_bytes, device, src)
     else:
-        dist.barrier()
+        _barrier(device_index)
         t0 = time.perf_counter()
         blob = broadcast_blob(None, eng.packed_bytes, device, src)
         eng.import_packed(blob)

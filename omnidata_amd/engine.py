@@ -192,6 +192,10 @@ class Engine:
         self.cfg = cfg
         self.fp8_calibrated = False
         self.fp8_scales = None  # the scales installed last (calibrate_fp8 / set_fp8_calibration): what a rebuilt engine re-installs
+        # per-layer precision overrides made through set_layer_precision, in call order: handle state that is NOT part of the
+        # packed weights, so every handle that is meant to compute what this one computes (ForwardPipeline.from_engine, an
+        # engine rebuilt for a larger input) replays them
+        self.layer_precision: Dict[str, int] = {}
         self.dtype = dtype
         self.backbone = backbone
         self.h = _vp()
@@ -329,6 +333,13 @@ class Engine:
     def set_layer_precision(self, conv_weight_key: str, mfmas: int):
         """dtype 'mixed': run one decoder convolution with 1 or 3 MFMAs per product (include/dptx.h)."""
         self._check(self.lib.dptx_set_layer_precision(self.h, conv_weight_key.encode(), int(mfmas)), "set_layer_precision")
+        self.layer_precision.pop(conv_weight_key, None)   # keep call order: a repeated key moves to the end
+        self.layer_precision[conv_weight_key] = int(mfmas)
+
+    def copy_layer_precision_from(self, other: "Engine"):
+        """Replays `other`'s set_layer_precision calls on this handle (same order)."""
+        for k, v in other.layer_precision.items():
+            self.set_layer_precision(k, v)
 
     # ---- fp8 dtype: per-tensor activation scales (include/dptx.h dptx_calibrate_fp8)
     def calibrate_fp8(self, x: torch.Tensor):

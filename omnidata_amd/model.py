@@ -95,8 +95,9 @@ class _EngineGuards:
         eng.calibrate_fp8(x[: self._chunk()])
         self._fp8_scales = (self._values_version, eng.fp8_scales)
 
-    def _range_fallback_needed(self, eng, x: torch.Tensor, rerun=None) -> bool:
-        """Called after a forward.  True: the engine left the fp16 range, the model has switched to bf16 planes and the
+    def _range_fallback_needed(self, eng, x: torch.Tensor, rerun=None, engines=None, pre_sync=None) -> bool:
+        """Called after a forward.  `engines` (forward_pipelined): every handle whose sticky flag belongs to this model's
+        forwards -- all of them are read and reset, after `pre_sync()` has drained their streams.  True: the engine left the fp16 range, the model has switched to bf16 planes and the
         caller recomputes the batch.  `rerun()` repeats the forward of THIS batch on the same engine: the device flag is
         sticky over up to `range_check_every` forwards, so a periodic read that finds it set cannot tell the arithmetic
         from a NaN / Inf INPUT image in an earlier batch -- the current, finite batch is run once more on the
@@ -109,7 +110,12 @@ class _EngineGuards:
         if not first and self._since_range_check < self.range_check_every:
             return False
         n_since, self._since_range_check = self._since_range_check, 0
-        if not eng.range_overflowed(reset=True):
+
+        def overflowed() -> bool:
+            if pre_sync is not None:
+                pre_sync()
+            return any([e.range_overflowed(reset=True) for e in (engines or [eng])])   # a list: every flag is reset
+        if not overflowed():
             self._range_checked = tag
             return False
         if not bool(torch.isfinite(x).all()):
@@ -117,7 +123,7 @@ class _EngineGuards:
         import warnings
         if not first and rerun is not None:
             rerun()
-            if not eng.range_overflowed(reset=True):
+            if not overflowed():
                 self._range_checked = tag
                 warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} saw non-finite activations in one of the previous "
                               f"{n_since - 1} forwards, but not on this (finite) batch run again: most likely a NaN / Inf input "
@@ -186,6 +192,7 @@ class DPTDepthModel(_EngineGuards, BaseModel):
             node.register_parameter(leaf, nn.Parameter(init[key], requires_grad=False))
         self._engine: Optional[Engine] = None
         self._engine_key = None
+        self._pipe, self._pipe_key = None, None   # forward_pipelined's cached ForwardPipeline
         self._weights_version = 0
         if path is not None:
             self.load(path)
@@ -199,38 +206,83 @@ class DPTDepthModel(_EngineGuards, BaseModel):
 
     @torch.no_grad()
     def forward_pipelined(self, batches, depth: int = 2):
-        """Throughput form of ``model(x)`` for a STREAM of batches (each [B,3,H,W], B <= max_batch, 384x384 or any one size the
-        engine is planned for): a generator of the results in order, with ``depth`` whole-batch forwards in flight on the GPU
-        (omnidata_amd/pipeline.py: +8 % images/s at B = 32 over calling the model batch by batch; each result is bit-identical
-        to ``model(x)``).  The fp16 range guard of ``forward`` does not run per batch here: the flags of the pipeline's handles
-        are read once at the end and reported with a warning (no automatic dtype switch)."""
-        from .pipeline import ForwardPipeline
-        pipe = None
+        """Throughput form of ``model(x)`` for a STREAM of batches (each [B,3,H,W], any B -- batches larger than ``max_batch`` are
+        chunked as in ``forward`` --, 384x384 or any one size the engine is planned for): a generator of the results in order,
+        with ``depth`` whole-batch forwards in flight on the GPU (omnidata_amd/pipeline.py; each result is bit-identical to
+        ``model(x)``).  The pipeline (``depth`` arenas next to the model's own engine) is cached on the model and rebuilt only
+        when the engine is (new weights, ``.to()``, another dtype, a larger input).  The fp16 range guard runs at ``forward``'s
+        cadence -- on the first batch of a set of weights and every ``range_check_every``-th one the pipeline is drained and every
+        handle's flag is read BEFORE the batch is yielded; on overflow the model switches to bf16 planes exactly as ``forward``
+        does and the batches still in flight are recomputed through ``forward`` (results already yielded since the previous
+        check may be affected, which the warning says)."""
+        pending = []   # (x, y, tickets) in submission order
+
+        def finish(entry):
+            for t in entry[2]:
+                t.wait()
+            return entry[1]
+
+        def retire(entry):
+            """-> list of results to yield for `entry` (and, after a dtype switch, for everything that was still in flight)."""
+            x, y, _ = entry
+            pipe = self._pipe
+            finish(entry)
+
+            def rerun():   # the same batch once more on one handle, on the current stream
+                step = self._chunk()
+                for i in range(0, x.shape[0], step):
+                    pipe.engines[0].forward(x[i:i + step], out=y[i:i + step])
+            if self._range_fallback_needed(pipe.engines[0], x, rerun, engines=pipe.engines, pre_sync=pipe.synchronize):
+                redo = [entry] + pending[:]
+                del pending[:]
+                self._drop_pipeline()
+                return [self.forward(e[0]) for e in redo]   # on the bf16-plane engine (forward squeezes)
+            return [y.squeeze(dim=1)]
+
         try:
-            pending = []
             for x in batches:
                 if not x.is_cuda:
                     raise RuntimeError("omnidata_amd.DPTDepthModel runs only on an AMD GPU (HIP); there is no CPU fallback")
-                if pipe is None:
-                    eng = self._get_engine(x.device)
-                    self._ensure_fp8(eng, x[: self._chunk()])
-                    pipe = ForwardPipeline.from_engine(eng, depth=depth)
-                pending.append(pipe.submit(x))
+                if x.dim() != 4 or x.shape[2] % 32 or x.shape[3] % 32:
+                    raise ValueError(f"expected [B,3,H,W] with H, W multiples of 32, got {tuple(x.shape)}")
+                B, _, H, W = x.shape
+                if H * W > self.max_hw[0] * self.max_hw[1]:
+                    for e in pending:     # the arena is re-planned: finish what runs on the old one first
+                        finish(e)
+                    self.max_hw = (H, W)
+                pipe = self._get_pipeline(x.device, depth, x)
+                step = self._chunk()
+                y = torch.empty(B, self.num_channels, H, W, dtype=_io_dtype(x), device=x.device)
+                pending.append((x, y, [pipe.submit(x[i:i + step], out=y[i:i + step]) for i in range(0, B, step)]))
                 if len(pending) >= depth:
-                    yield pending.pop(0).wait().squeeze(dim=1)
+                    for r in retire(pending.pop(0)):
+                        yield r
             while pending:
-                yield pending.pop(0).wait().squeeze(dim=1)
-            if pipe is not None and self.overflow_fallback and self.engine_dtype in self._FP16_FALLBACK:
-                pipe.synchronize()
-                if any(e.range_overflowed(reset=True) for e in pipe.engines):
-                    import warnings
-                    warnings.warn(f"omnidata_amd: dtype={self.engine_dtype!r} produced non-finite activations in forward_pipelined "
-                                  f"(fp16 range exceeded, or a non-finite input); results may be affected -- model(x) falls back to "
-                                  f"bf16 planes by itself, the pipelined form does not.")
+                for r in retire(pending.pop(0)):
+                    yield r
         finally:
-            if pipe is not None:
-                pipe.synchronize()
-                pipe.close()
+            if self._pipe is not None:
+                self._pipe.synchronize()
+
+    def _get_pipeline(self, device: torch.device, depth: int, x: Optional[torch.Tensor] = None):
+        """The cached ForwardPipeline over the model's engine (not one per call -- `depth` arenas of 5.2 GB at
+        B = 32, a hipMalloc / hipFree and stream creation each time)."""
+        from .pipeline import ForwardPipeline
+        eng = self._get_engine(device)
+        if x is not None:
+            self._ensure_fp8(eng, x[: self._chunk()])
+        key = (self._engine_key, int(depth), tuple(sorted(eng.layer_precision.items())),
+               None if eng.fp8_scales is None else eng.fp8_scales.tobytes())
+        if self._pipe is None or self._pipe_key != key or self._pipe._external_owner is not eng:
+            self._drop_pipeline()
+            self._pipe, self._pipe_key = ForwardPipeline.from_engine(eng, depth=depth), key
+        return self._pipe
+
+    def _drop_pipeline(self):
+        if getattr(self, "_pipe", None) is not None:
+            self._pipe.synchronize()
+            self._pipe.close()
+        self._pipe, self._pipe_key = None, None
 
     def _apply(self, fn, *a, **kw):
         r = super()._apply(fn, *a, **kw)
@@ -241,6 +293,7 @@ class DPTDepthModel(_EngineGuards, BaseModel):
         key = (device.index if device.index is not None else torch.cuda.current_device(),
                self._weights_version, self.engine_dtype, self._chunk(), self.max_hw)
         if self._engine is None or self._engine_key != key:
+            self._drop_pipeline()   # its handles read the old engine's weights and arena plan
             if self._engine is not None:
                 self._engine.close()
             eng = Engine(num_channels=self.num_channels, max_batch=self._chunk(), dtype=self.engine_dtype,

@@ -92,6 +92,7 @@ class ForwardPipeline:
                    flags=c.flags)
         for e in self.engines:
             e.share_weights_from(owner)
+            e.copy_layer_precision_from(owner)   # per-layer precision is handle state, not part of the shared blob
             if owner.fp8_scales is not None:
                 e.set_fp8_calibration(owner.fp8_scales)
         self._external_owner = owner

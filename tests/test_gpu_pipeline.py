@@ -127,3 +127,63 @@ def test_pipelined_stress_b32_bit_identical(dtype):
     pipe.close()
     eng.close()
     assert bad == 0, f"{bad} of 120 pipelined forwards differ from the forward computed alone"
+
+
+def test_pipeline_from_engine_replays_layer_precision_bitwise():
+    """per-layer precision set on the owner (dptx_set_layer_precision) is handle state, not part of the shared blob --
+    ForwardPipeline.from_engine must replay it, or the pipelined results are the DEFAULT table's (and bench.py's
+    parity_mode_head0_2mfma line would time one table and check another)."""
+    sd = random_state_dict(0, 3)
+    own = Engine(num_channels=3, max_batch=4, dtype="mixed", device_id=0)
+    own.load_state_dict(sd)
+    x = synthetic_input(31, 4, "normal").to(DEV)
+    y_default = own.forward(x).clone()
+    own.set_layer_precision("scratch.output_conv.0.weight", 2)
+    y_two = own.forward(x).clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(y_default, y_two)          # the override changes the arithmetic ...
+    pipe = ForwardPipeline.from_engine(own, depth=2)
+    assert all(e.layer_precision == {"scratch.output_conv.0.weight": 2} for e in pipe.engines)
+    outs = list(pipe.map([x, x, x]))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, y_two) for o in outs)   # ... and the pipeline's handles compute what the owner computes
+    pipe.close()
+    own.close()
+
+
+def test_rejected_import_leaves_the_handle_as_it_was():
+    """dptx_import_packed_device validates the incoming blob's layout header BEFORE it un-shares / re-allocates: a
+    handle that shares another's weights keeps them (and keeps working) when the import is refused."""
+    lib = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    lib.load_state_dict(random_state_dict(0, 3))
+    sharer = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    sharer.share_weights_from(lib)
+    x = synthetic_input(6, 2, "normal").to(DEV)
+    y0 = lib.forward(x).clone()
+    bad = lib.export_packed().clone()
+    bad[:8] = 0   # not a DPTXBLOB header
+    with pytest.raises(RuntimeError, match="another layout"):
+        sharer.import_packed(bad)
+    assert torch.equal(sharer.forward(x), y0) and torch.equal(lib.forward(x), y0)
+    assert torch.equal(sharer.export_packed(), lib.export_packed())   # still the shared blob
+    with pytest.raises(RuntimeError, match="another layout"):
+        lib.import_packed(bad)                                        # the owner, whose blob somebody else reads
+    assert torch.equal(lib.forward(x), y0) and torch.equal(sharer.forward(x), y0)
+    sharer.close()
+    lib.close()
+
+
+def test_model_forward_pipelined_caches_chunks_and_matches_model():
+    """DPTDepthModel.forward_pipelined: one cached pipeline per engine, batches above max_batch chunked like
+    model(x), results bit-identical to model(x)."""
+    model = DPTDepthModel(num_channels=3, dtype="mixed", max_batch=4, init_seed=0).eval()
+    xs = [synthetic_input(40 + i, b, "normal").to(DEV) for i, b in enumerate((4, 9, 2))]   # 9 > max_batch
+    refs = [model(x).clone() for x in xs]
+    got = list(model.forward_pipelined(xs, depth=2))
+    pipe = model._pipe
+    assert pipe is not None and len(got) == 3 and all(torch.equal(g, r) for g, r in zip(got, refs))
+    got2 = list(model.forward_pipelined(xs[:2], depth=2))
+    assert model._pipe is pipe and all(torch.equal(g, r) for g, r in zip(got2, refs))    # same pipeline, no re-allocation
+    model.load_state_dict(random_state_dict(1, 3))                                       # new weights: the engine and its pipeline go
+    got3 = list(model.forward_pipelined(xs[:1], depth=2))
+    assert model._pipe is not pipe and not torch.equal(got3[0], refs[0]) and torch.equal(got3[0], model(xs[0]))

@@ -354,6 +354,66 @@ def test_fp16_overflow_fallback_control_flow(monkeypatch):
     assert model.engine_dtype == "mixed" and ("forward", 3) in engines[0].calls
 
 
+class _StubPipe:
+    """Stands in for omnidata_amd.pipeline.ForwardPipeline over stub engines: submissions go round robin and run at once."""
+    def __init__(self, engines):
+        self.engines, self._next, self.closed, self.syncs = engines, 0, False, 0
+
+    def submit(self, x, out=None):
+        e = self.engines[self._next % len(self.engines)]
+        self._next += 1
+        e.forward(x, out=out)
+
+        class T:
+            def wait(self_inner):
+                return out
+        return T()
+
+    def synchronize(self):
+        self.syncs += 1
+
+    def close(self):
+        self.closed = True
+
+
+def test_forward_pipelined_chunks_caches_and_guards(monkeypatch):
+    """Host logic of DPTDepthModel.forward_pipelined: batches above max_batch are chunked, the range guard runs
+    at forward's cadence over EVERY handle's flag, and on overflow the model leaves the fp16 planes and recomputes what
+    was still in flight through forward()."""
+    import warnings
+    x9 = torch.rand(9, 3, 64, 64).as_subclass(_FakeCudaTensor)
+    x2 = torch.rand(2, 3, 64, 64).as_subclass(_FakeCudaTensor)
+    # healthy weights: 9 images with max_batch 4 -> chunks 4, 4, 1 round robin over the two handles; flags read once
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=False)
+    pipes = []
+
+    def get_pipeline(device, depth, x=None):
+        if not pipes or pipes[-1].closed or pipes[-1].engines[0].dtype != model.engine_dtype:
+            pipes.append(_StubPipe([_StubEngine(model.engine_dtype, engines_overflow[0]) for _ in range(depth)]))
+        model._pipe = pipes[-1]
+        return pipes[-1]
+    engines_overflow = [False]
+    monkeypatch.setattr(model, "_get_pipeline", get_pipeline)
+    out = list(model.forward_pipelined([x9, x2, x2], depth=2))
+    assert [tuple(o.shape) for o in out] == [(9, 3, 64, 64), (2, 3, 64, 64), (2, 3, 64, 64)]
+    calls = [c for e in pipes[0].engines for c in e.calls]
+    assert sorted(c[1] for c in calls if c[0] == "forward") == [1, 2, 2, 4, 4]
+    assert calls.count(("range", True)) == 2 and len(pipes) == 1   # both handles' flags, once (first batch of these weights)
+    # overflowing weights: first batch's check finds the flags set -> bf16x3, the batch and the one in flight go through forward()
+    model, engines = _stubbed_model(monkeypatch, "mixed", overflow=True)
+    pipes.clear()
+    engines_overflow[0] = True
+    monkeypatch.setattr(model, "_get_pipeline", get_pipeline)
+    monkeypatch.setattr(model, "_drop_pipeline", lambda: [p.close() for p in pipes] and None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = list(model.forward_pipelined([x2, x2, x2], depth=2))
+    assert len(out) == 3 and model.engine_dtype == "bf16x3"
+    assert any("switching this model" in str(m.message) for m in w)
+    assert engines[-1].dtype == "bf16x3" and engines[-1].calls.count(("forward", 2)) >= 2   # recomputed on the fallback engine
+    assert pipes[0].closed and pipes[0].syncs >= 1
+
+
 def test_fp8_calibration_is_explicit_or_announced_and_survives_engine_rebuilds(monkeypatch):
     """implicit calibration on the first batch warns; the scales belong to the weights -- a rebuilt
     engine (.to(), larger input) gets them back without a new calibration, new weights drop them."""
