@@ -57,6 +57,74 @@ def spawn_command(n_gpus, argv, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+FAMILY_KERNELS = ("gemm_glds_kernel", "gemm_pp_kernel", "gemm_pp2_kernel", "gemm_reg_kernel", "stem_conv_kernel", "head_tail_kernel",
+                  "head_tail_x3_kernel")
+
+
+def measure_traffic(args, lib_hash):
+    """Two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, --kernel-trace only, as MI355X_MICROARCH.md's HBM
+    section prescribes) over `bench.py --traffic-child` (whole-batch forwards, one at a time on one stream), summed per kernel
+    family from the rocpd databases.  Forwards are COUNTED in the trace (launches of the first kernel of a forward), not assumed.
+    Returns the dict that profiles/r0N_pmc_traffic.json holds, or None."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        print("measure_traffic: rocprofv3 not found", file=sys.stderr)
+        return None
+    tmp = tempfile.mkdtemp(prefix="dptx_traffic_", dir="/tmp")
+    env = dict(os.environ, DPTX_STREAMS="1", DPTX_STAGE_GROUPS="1", TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--steps", "3", "--batch", str(args.batch), "--dtype", args.dtype,
+             "--task", args.task, "--backbone", args.backbone, "--io", args.io]
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([rocprof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "r", "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                print(f"measure_traffic: rocprofv3 --pmc {counter} failed (rc {r.returncode})\n{r.stdout[-2000:]}", file=sys.stderr)
+                return None
+            cur = sqlite3.connect(dbs[0]).cursor()
+            fam = allk = 0.0
+            for name, cname, val in cur.execute("select name, counter_name, counter_value from pmc_events"):
+                if cname != counter:
+                    continue
+                allk += val
+                if any(f in name for f in FAMILY_KERNELS):
+                    fam += val
+            # forwards and family launches are COUNTED in the kernel trace of the same run (a counter may have several rows per dispatch)
+            names = [r[0] for r in cur.execute("select name from kernels")]
+            forwards = sum(1 for n in names if "stem_conv_kernel" in n or "patchify16_kernel" in n)
+            gemm_launches = sum(1 for n in names if any(f in n for f in FAMILY_KERNELS))
+            sums[counter] = (fam, allk, forwards, gemm_launches)
+    except Exception as ex:   # the headline must not die with an optional measurement
+        print(f"measure_traffic: {type(ex).__name__}: {ex}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    (f_fam, f_all, fw, nl), (w_fam, w_all, fw2, _) = sums["FETCH_SIZE"], sums["WRITE_SIZE"]
+    if fw < 1 or fw2 < 1:
+        print("measure_traffic: no forward found in the trace", file=sys.stderr)
+        return None
+    corr = 2.0   # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM)
+    fam_bytes = corr * f_fam * 1024.0 / fw + w_fam * 1024.0 / fw2
+    all_bytes = corr * f_all * 1024.0 / fw + w_all * 1024.0 / fw2
+    launches = nl / fw
+    return {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, DPTX_STREAMS=1 DPTX_STAGE_GROUPS=1, bench.py "
+                      f"--traffic-child B={args.batch} {args.dtype} {args.task}",
+            "library": lib_hash, "forwards": fw, "gemm_family_fetch_kb_raw_per_forward": f_fam / fw,
+            "gemm_family_write_kb_per_forward": w_fam / fw2, "gfx950_fetch_correction": corr,
+            "gemm_family_hbm_bytes_per_forward": fam_bytes, "all_kernels_hbm_bytes_per_forward": all_bytes,
+            "gemm_launches_per_forward": launches, "gemm_family_hbm_bytes_per_launch": fam_bytes / launches}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,13 +145,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the short secondary measurements (depth, dual-task bf16 / fp8) "
                                                             "that the default N = 1 normal-head run appends under 'also'")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="batches in flight per GPU in the timed loop (omnidata_amd/pipeline.py ForwardPipeline: that many handles, "
-                         "one stream each, one shared copy of the weights; every step is still one forward of one batch of --batch "
-                         "images).  1 = round 4's schedule: one forward at a time, its two halves on two streams.  The line "
-                         "carries the other schedule's number from the same run under config.schedule_ab")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="batches in flight per GPU in the HEADLINE loop.  Default (not given): 1 = what the drop-in call `model(x)` / "
+                         "`torch.hub.load(...)(x)` delivers -- one forward at a time, stream-ordered.  n > 1: omnidata_amd/pipeline.py "
+                         "ForwardPipeline (that many handles, one stream each, one shared copy of the weights; every step is still one "
+                         "forward of one batch of --batch images; batch latency ~ n x ms_per_step, n arenas).  At N = 1 BOTH schedules "
+                         "are timed in the same process and reported as value_inflight1 / value_inflight2; `value` is the headline's")
     ap.add_argument("--no-schedule-ab", action="store_true", help="skip the other schedule's loop (rocprofv3 passes: one schedule per trace)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="N = 1: measure roofline.traffic in THIS run -- two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate "
+                         "child processes of this script, a few single-stream forwards each; + ~2 min) instead of reading the committed "
+                         "measurement; --traffic-out writes the result (stamped with the library's source hash) for later runs")
+    ap.add_argument("--traffic-out", default=None, help="with --measure-traffic: JSON file to write (e.g. profiles/r06_pmc_traffic.json)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--profile-dump", default=None, help="write per-launch CSV of one profiled forward here")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (functional test of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: all ranks use cuda:0 (needs --dist-backend gloo)")
@@ -95,6 +170,9 @@ def main():
                     help="launch the N ranks, count them with one all-reduce (gloo, no GPU touched), print {n_gpus, ranks_seen} "
                          "and exit: the CPU test of the --gpus N launch path")
     args = ap.parse_args()
+    inflight_explicit = args.inflight is not None
+    if args.inflight is None:
+        args.inflight = 1
 
     # --gpus N is the number of ranks.  Under a launcher (torch.distributed.run: the driver's N > 1 form) WORLD_SIZE is set and
     # must agree; a plain `python bench.py --gpus N` starts the N ranks itself by re-executing under torch.distributed.run.
@@ -190,12 +268,23 @@ def main():
         from omnidata_amd.dist import broadcast_fp8_calibration
         broadcast_fp8_calibration(eng, x, device)
 
+    if args.traffic_child:   # under rocprofv3 --pmc (see measure_traffic): whole-batch forwards, one at a time, then exit
+        for _ in range(max(1, args.steps)):
+            eng.forward(x, out=y)
+        torch.cuda.synchronize()
+        return
+
     # the timed loop: K steps, each ONE forward of one batch; with --inflight n > 1 consecutive steps go to n handles on n
     # streams (one copy of the weights) and overlap -- every step is enqueued inside the timed region and complete at its end
     from omnidata_amd.pipeline import ForwardPipeline
+    from omnidata_amd.telemetry import GpuTelemetry
+    tele = GpuTelemetry(local_rank) if rank == 0 else None
+    tele_idle = tele.read_once() if tele is not None else None
+    tele_log = {}
 
-    def timed(e_, inflight, steps, warmup, x_, y_, dual_=False, y2_=None):
-        """seconds for `steps` forwards of x_ on engine e_ (weights loaded) with `inflight` forwards in flight, all finite?"""
+    def timed(e_, inflight, steps, warmup, x_, y_, dual_=False, y2_=None, tag=None):
+        """seconds for `steps` forwards of x_ on engine e_ (weights loaded) with `inflight` forwards in flight, all finite?
+        tag: record the GPU's clock / power / temperature over the timed region under tele_log[tag] (sampling thread, no GPU work)"""
         pipe = ForwardPipeline.from_engine(e_, depth=inflight) if inflight > 1 else None
         ys_ = [y_] + [torch.empty_like(y_) for _ in range(inflight - 1)]
         y2s_ = ([y2_] + [torch.empty_like(y2_) for _ in range(inflight - 1)]) if dual_ else None
@@ -214,28 +303,31 @@ def main():
         for i in range(max(warmup, inflight)):
             one(i)
         sync_all()
+        if tag is not None and tele is not None:
+            tele.start()
         t_ = time.perf_counter()
         for i in range(steps):
             one(i)
         sync_all()
         dt_ = time.perf_counter() - t_
+        if tag is not None and tele is not None:
+            tele_log[tag] = tele.stop().summary()
         ok_ = all(bool(torch.isfinite(t.float()).all()) for t in ys_)
         if pipe is not None:
             pipe.close()
         return dt_, ok_
 
-    # The other schedule first (rank 0, N = 1), the headline last: what --inflight buys on THIS box in THIS process.  (First, so
-    # that the engine's two internal streams exist before the pipeline's: measured the other way round -- lease r5l3 -- the
-    # one-forward-at-a-time loop ran at 1993 instead of ~2600 images/s, i.e. its two half-batch streams no longer overlapped;
-    # HIP maps streams onto a small number of hardware queues in creation order.)
+    # The other schedule first (rank 0, N = 1), the headline last: both schedules on THIS box in THIS process.  (First, so
+    # that the engine's internal streams exist before the pipeline's: measured the other way round -- lease r5l3 -- the
+    # one-forward-at-a-time loop ran at 1993 instead of ~2600 images/s; HIP maps streams onto a small number of hardware queues.)
     schedule_ab = None
     if rank == 0 and world == 1 and not args.no_schedule_ab:
         other = 1 if args.inflight > 1 else 2
-        dt_o, _ = timed(eng, other, args.steps, args.warmup, x, y, dual, y2 if dual else None)
+        dt_o, _ = timed(eng, other, args.steps, args.warmup, x, y, dual, y2 if dual else None, tag=f"inflight{other}")
         schedule_ab = {"inflight": other, "value": round(args.batch * args.steps / dt_o, 2), "unit": "images/s",
                        "ms_per_step": round(1e3 * dt_o / args.steps, 3),
                        "note": "same process, same weights, measured right before the headline loop"}
-    elapsed, finite = timed(eng, args.inflight, args.steps, args.warmup, x, y, dual, y2 if dual else None)
+    elapsed, finite = timed(eng, args.inflight, args.steps, args.warmup, x, y, dual, y2 if dual else None, tag=f"inflight{args.inflight}")
     assert finite
     # what proves that N ranks ran, each on its own GPU: an all-reduce of 1, every rank's device index and own clock
     ranks_seen, rank_devices, per_rank = 1, [local_rank], [args.batch * args.steps / elapsed]
@@ -273,15 +365,33 @@ def main():
         gemm_ms = acc["gemm"][0] / P
         gemm_flop = 2.0 * GEMM_GMAC_PER_IMAGE[args.task] * 1e9 * args.batch
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
-        # HBM traffic of the family per launch: PMC counters cannot be read inside this process, so the
-        # figure is the committed rocprofv3 measurement of this very command (profiles/README.md), scaled
-        # from its batch to this one; null when no measurement is committed for the dtype.
-        traffic = None
-        for name in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json", "r04_pmc_traffic.json", "r05_pmc_traffic.json"):  # newest committed round wins
-            tpath = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(tpath) and args.dtype == "bf16" and not large:
-                tj = json.load(open(tpath))
-                traffic = round(tj["gemm_family_hbm_bytes_per_launch"] * args.batch / 32.0)
+        # HBM traffic of the family per launch.  PMC counters cannot be read inside this process: either --measure-traffic
+        # runs the two rocprofv3 passes as child processes NOW, or the newest committed measurement (profiles/r0N_pmc_traffic.json)
+        # is used -- but only if it was taken on THIS library (its "library" stamp equals dptx_version()'s src hash); a figure
+        # measured on other kernels is reported as null with the reason, not passed off as this run's
+        lib_hash = eng.lib.dptx_version().decode().rsplit("src=", 1)[-1]
+        traffic, traffic_src = None, None
+        if args.measure_traffic and world == 1:
+            tj = measure_traffic(args, lib_hash)
+            if tj is not None:
+                traffic = round(tj["gemm_family_hbm_bytes_per_launch"])
+                traffic_src = "measured in this run: " + tj["source"]
+                if args.traffic_out:
+                    with open(args.traffic_out, "w") as f:
+                        json.dump(tj, f, indent=1)
+            else:
+                traffic_src = "--measure-traffic failed (rocprofv3 unavailable or its output unreadable): see stderr"
+        else:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+            if cands and args.dtype == "bf16" and not large and args.task == "normal":
+                tj = json.load(open(cands[-1]))   # newest committed round
+                if tj.get("library") == lib_hash:
+                    traffic = round(tj["gemm_family_hbm_bytes_per_launch"] * args.batch / 32.0)
+                    traffic_src = f"committed measurement {os.path.basename(cands[-1])} on this library ({lib_hash}), B=32"
+                else:
+                    traffic_src = (f"null: {os.path.basename(cands[-1])} was measured on library {tj.get('library', '(unstamped, rounds 1-5)')}, "
+                                   f"this run's is {lib_hash}; run `python bench.py --measure-traffic` for a figure of this build")
         # the fraction is quoted for the single-pass 16-bit modes only: fp8 runs part of the family on the 2x-rate e4m3 MFMA
         # and the 3-MFMA modes execute up to three products per algorithmic one, so "achieved / bf16 peak" would not be a
         # utilisation figure there
@@ -291,9 +401,10 @@ def main():
                     "frac": round(achieved / PEAK_TFLOPS, 4) if single_pass else None,
                     "frac_note": None if single_pass else "not quoted: algorithmic FLOP/s of a mode that runs part of the family on "
                                  "the fp8 MFMA (2x peak) or with 3 MFMAs per product is not a utilisation of the bf16 peak",
-                    "traffic": traffic,
-                    "traffic_note": "HBM bytes per gemm launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from the committed "
-                                    "rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json, newest round); algorithmic min ~ A+C+W bytes",
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_note": "HBM bytes per gemm launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from rocprofv3 PMC passes "
+                                    "(separate passes; gfx950 FETCH_SIZE x2: MI355X_MICROARCH.md HBM); algorithmic min ~ A+C+W bytes "
+                                    "= 16.64 GB / 130 launches = 128 MB per launch at B=32",
                     "launches_per_step": acc["gemm"][1], "avg_launch_ms": round(gemm_ms / max(1, acc["gemm"][1]), 5),
                     "algorithmic_gflop_per_step": round(gemm_flop / 1e9, 1),
                     "executed_gflop_per_step": round(2 * acc["gemm"][2] * args.batch / 1e9, 1)}
@@ -314,12 +425,14 @@ def main():
         # oneDNN/MKL at batch 4 stop scaling (and then collapse) well before 256 threads: probe a few
         # thread counts on one batch each and keep the fastest for the timed sample
         best, best_t = None, None
-        for nt in sorted({min(ncpu, n) for n in (16, 32, 64, 128)}):
+        tried = {}
+        for nt in sorted({min(ncpu, n) for n in (16, 32, 64, 128, 256)}):
             torch.set_num_threads(nt)
             dpt_forward(sd, xc[:1])
             t1 = time.perf_counter()
             dpt_forward(sd, xc)
             dt1 = time.perf_counter() - t1
+            tried[nt] = round(xc.shape[0] / dt1, 3)
             if best_t is None or dt1 < best_t:
                 best, best_t = nt, dt1
             if dt1 > 20:
@@ -335,10 +448,14 @@ def main():
         dt_cpu = time.perf_counter() - t1
         cpu_baseline = {"value": round(n_img / dt_cpu, 3), "unit": "images/s", "cores": best, "host_logical_cpus": ncpu,
                         "kind": "port",
+                        "threads_tried_images_per_s": tried,
+                        "threads_note": "north_star asks for all host cores: every count in threads_tried was timed on one batch of 4 "
+                                        "and the fastest kept -- oneDNN at this batch size is slower on more threads, so `cores` is the "
+                                        "count that gives the CPU its best number, of host_logical_cpus available",
                         "kind_note": "oracle/dpt_oracle.py: functional restatement of the reference forward, pinned at 0.0 against "
                                      "the reference's unmodified modules + timm shim by oracle/validate_vs_reference.py",
                         "sample": f"{n_img} images (batches of 4) of the same synthetic 384x384 workload, fp32, "
-                                                  f"best of 16/32/64/128 threads"}
+                                                  f"best of {sorted(tried)} threads"}
 
     # ---- parity: the benched dtype AND the parity mode against the fp32 oracle on the cpu_baseline sample, and the parity
     # mode's own throughput (same batch, same timing protocol), so that "matches the reference" and "img/s" are stated
@@ -365,7 +482,9 @@ def main():
                                      "ms_per_step": round(1e3 * pdt / args.steps, 3), "max_abs": round(pm, 6),
                                      "meets_1e-3": bool(pm < 1e-3), "inflight": args.inflight,
                                      "schedule_ab": {"inflight": 1 if args.inflight > 1 else 2,
-                                                     "value": round(args.batch * args.steps / pdt1, 2)}}
+                                                     "value": round(args.batch * args.steps / pdt1, 2)},
+                                     "value_inflight1": round(args.batch * args.steps / (pdt if args.inflight == 1 else pdt1), 2),
+                                     "value_inflight2": round(args.batch * args.steps / (pdt1 if args.inflight == 1 else pdt), 2) if args.inflight <= 2 else None}
             if args.parity_dtype == "mixed" and not args.parity_x3_groups:
                 # the measured option outside the default table (include/dptx.h dptx_set_layer_precision): the first head
                 # convolution on two MFMAs -- weights exact, input rounded once
@@ -400,6 +519,7 @@ def main():
             if dtype2.startswith("fp8"):
                 e2.calibrate_fp8(x2)
             n2 = max(4, min(args.steps, 20))
+            dt2o, _ = timed(e2, 1 if args.inflight > 1 else 2, n2, 3, x2, ya, d2, yb if d2 else None)   # the other schedule
             dt2, _ = timed(e2, args.inflight, n2, 3, x2, ya, d2, yb if d2 else None)    # the headline's schedule
             max_abs2 = None
             if dtype2 == "mixed" and not args.no_cpu_baseline:   # the dual-task parity mode against the oracle (2 images, both heads)
@@ -410,6 +530,8 @@ def main():
                 max_abs2 = round(max(float((ya[:2].float().cpu() - rn).abs().max()), float((yb[:2, 0].float().cpu() - rd).abs().max())), 6)
             also.append({"workload": f"DPT-Hybrid-384 {task2}, batch {args.batch}, {dtype2}, 1xMI355X (BASELINE.json configs[{cfg_i}])",
                          "task": task2, "dtype": dtype2, "value": round(args.batch * n2 / dt2, 2), "unit": "images/s", "inflight": args.inflight,
+                         "value_inflight1": round(args.batch * n2 / (dt2 if args.inflight == 1 else dt2o), 2),
+                         "value_inflight2": round(args.batch * n2 / (dt2o if args.inflight == 1 else dt2), 2) if args.inflight <= 2 else None,
                          "steps": n2, "ms_per_step": round(1e3 * dt2 / n2, 3),
                          "e2e_tflops_algorithmic": round(args.batch * n2 / dt2 * GFLOP_PER_IMAGE[task2] / 1e3, 1),
                          "max_abs_vs_oracle": max_abs2,
@@ -420,6 +542,13 @@ def main():
             e2.close()
             del e2, x2, ya, yb
             torch.cuda.empty_cache()
+        # fp8 is a throughput mode only where it is faster than the bf16 engine it approximates: say which it is on THIS box
+        dual_bf16 = next((a["value"] for a in also if a["task"] == "dual" and a["dtype"] == "bf16"), None)
+        for a in also:
+            if a["dtype"].startswith("fp8") and dual_bf16:
+                a["vs_dual_bf16"] = round(a["value"] / dual_bf16, 3)
+                a["verdict"] = ("faster than dual bf16 on this box" if a["value"] > 1.02 * dual_bf16 else
+                                "NOT faster than dual bf16 on this box (within 2 % or slower): no reason to accept its accuracy loss here")
 
     if rank == 0:
         total_images = args.batch * world * args.steps
@@ -431,6 +560,16 @@ def main():
                        "depth": f"images/sec (384x384) {arch} depth inference",
                        "dual": "images/sec (384x384) DPT-Hybrid dual-task normal+depth, shared encoder"}[args.task],
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # both schedules as first-class numbers of this process (N = 1): inflight1 = what `model(x)` / the hub call delivers,
+            # inflight2 = ForwardPipeline / model.forward_pipelined (two arenas, ~2x batch latency).  `value` is value_inflight<headline>
+            "value_inflight1": (round(value, 2) if args.inflight == 1 else (schedule_ab or {}).get("value")) if world == 1 else None,
+            "value_inflight2": (round(value, 2) if args.inflight == 2 else ((schedule_ab or {}).get("value") if args.inflight == 1 else None)) if world == 1 else None,
+            "headline_schedule": (f"--inflight {args.inflight} given explicitly" if inflight_explicit else
+                                  "default: inflight 1 = the drop-in call model(x), one forward at a time"),
+            "telemetry": {"idle_before": tele_idle, **tele_log,
+                          "note": "GPU shader clock / board power / temperature sampled from sysfs by a host thread during each timed "
+                                  "loop (omnidata_amd/telemetry.py): the chip is power-managed, a number is comparable across boxes "
+                                  "and rounds only together with the clock it ran at"},
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "io_dtype": args.io,
             "data": "synthetic 384x384 inputs resident in HBM; seeded random weights",
@@ -444,14 +583,21 @@ def main():
                        "schedule": (f"{args.inflight} forwards of {args.batch} images in flight per GPU: {args.inflight} handles x 1 stream, one "
                                     f"shared copy of the weights (omnidata_amd/pipeline.py); batch latency ~ {args.inflight} x ms_per_step"
                                     if args.inflight > 1 else
-                                    "one forward at a time = two half-batches on two HIP streams of one GPU (DPTX_STREAMS=1: one stream)"),
+                                    "one forward at a time on the caller's stream (the engine's own intra-forward schedule: DESIGN.md 3)"),
                        "inflight": args.inflight, "schedule_ab": schedule_ab,
+                       # inflight 1: which intra-forward schedule the handle MEASURED to be faster at its first forward
+                       # (include/dptx.h dptx_tune_schedule): split = two half-batches on two internal streams
+                       "engine_schedule": eng.schedule_info(),
                        # A/B switches of the library that were set in this process's environment: none
                        # in a default run -- a stray one would otherwise change the kernels under the number unseen
                        "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DPTX_")}},
             "e2e_mfma_frac": round(e2e_tflops / (PEAK_TFLOPS * world), 4) if args.dtype in ("bf16", "fp16") else None,
             "e2e_tflops_algorithmic": round(e2e_tflops, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "also": also, "kernel_breakdown": breakdown,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "also": also,
+            "kernel_breakdown": None if breakdown is None else dict(breakdown, overlap_note=(
+                "per-launch HIP events of profiled forwards run one at a time on ONE stream after the timed region (every launch "
+                "serialised): the categories sum to the single-stream forward, which is LONGER than ms_per_step whenever the timed "
+                "schedule overlaps launches (image groups, two forwards in flight)")),
         }
     if world > 1 or args.dist_selftest:
         dist.barrier()

@@ -83,8 +83,9 @@ typedef struct dptx_config {
   int32_t max_height;    /* largest input the arena is planned for; 0 = 384. Multiples of 32,   */
   int32_t max_width;     /*   >= 64, and max_batch*max_height*max_width*256 < 2^31 (see dptx_forward_hw) */
   int32_t dual_task;     /* 1: two decoders on one shared encoder (see dptx_forward_dual); needs num_channels = 3 */
-  int32_t streams;       /* n = 2..4 (0 = 2): a forward of >= 2 images runs as n sub-batches on n internal streams, */
-                         /*   forked from / joined to the caller's stream (same bits, faster); 1: caller's stream only */
+  int32_t streams;       /* n = 2..4: a forward of >= 2 images runs as n sub-batches on n internal streams, forked   */
+                         /*   from / joined to the caller's stream (same bits); 1: caller's stream only; 0 (default):  */
+                         /*   MEASURED choice between 1 and 2 -- one stream until dptx_tune_schedule has timed both    */
   int32_t x3_groups;     /* dtype MIXED: OR of DPTX_GROUP_* that run with 3 MFMAs per product; 0 = the default policy  */
                          /*   (everything except the ViT blocks).  Ignored by the other dtypes.                      */
   int32_t backbone;      /* DPTX_BACKBONE_*: 0 = vitb_rn50_384 (DPT-Hybrid, the default), 1 = vitl16_384 (DPT-Large:  */
@@ -247,6 +248,26 @@ int dptx_enable_taps(dptx_handle h, int on);
  * is commuted in front of the x2 upsample). */
 int dptx_forward_info(dptx_handle h, int64_t* launches, double* algorithmic_macs,
                       double* executed_macs);
+
+/* Intra-forward schedule of a handle created with streams = 0 (round 6).  Whether two half-batches on two internal streams
+ * beat one whole-batch run depends on what the runtime does with the two streams on THIS box in THIS process (hardware-queue
+ * sharing, priorities: measured from +6 % to -25 %, profiles/r05_experiments.md, r06_experiments.md) -- so it is measured,
+ * not assumed: dptx_tune_schedule runs the forward of this very batch `reps` times per schedule (after one untimed run each),
+ * timed with HIP events on `stream`, keeps the two-stream schedule only if it is at least 3 % faster, and blocks until done.
+ * The result of either schedule is the same bits.  dptx_schedule_info reports the decision: *split = 1 two half-batches,
+ * 0 one stream; *tuned = 0 while nothing has been measured (one stream); ms_* = the measured times (0 before).
+ * Handles with streams >= 1 (or DPTX_STREAMS set) keep the schedule they were told: tune returns DPTX_OK without measuring.
+ * y_depth_dev: dual-task handles only (else NULL). */
+int dptx_tune_schedule(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, void* y_depth_dev, int32_t batch,
+                       int32_t height, int32_t width, int32_t reps, void* stream);
+int dptx_schedule_info(dptx_handle h, int32_t* split, int32_t* tuned, float* ms_single, float* ms_split);
+
+/* Do two streams of `device_id` actually run concurrently?  Work on two streams that the runtime has mapped onto ONE hardware
+ * queue executes in order (profiles/r05_experiments.md: 1974 instead of 2600 images/s), and nothing in the API says so.  The
+ * probe launches a sleeping one-wave kernel of `spin_us` microseconds (0 = 2000) on stream_a alone, then on both streams at
+ * once, host-timed: *ratio = t_both / t_alone -- ~1.0 concurrent, ~2.0 serialised.  Blocks (two stream synchronisations per
+ * measurement); both streams must be idle-able.  omnidata_amd/pipeline.py checks its slot streams with it. */
+int dptx_probe_stream_overlap(int32_t device_id, void* stream_a, void* stream_b, int32_t spin_us, float* ratio);
 
 /* Per-launch timing of the NEXT forwards with one HIP event after every launch on the forward's
  * stream (kernels of one forward are serialized, so consecutive events bracket one kernel plus

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -440,7 +441,11 @@ struct dptx_engine {
 
   // two sub-batches on two internal streams (MFMA-bound and HBM-bound launches of the two halves overlap, tails fill)
   static constexpr int MAX_STREAMS = 4;
-  int n_streams = 2;              // cfg.streams (0 = default 2); 1 = everything on the caller's stream
+  int n_streams = 2;              // cfg.streams (0 = auto: 2 streams exist, used only when measured faster); 1 = caller's stream
+  // cfg.streams == 0 and no DPTX_STREAMS: the two-half schedule is used only after dptx_tune_schedule measured it >= 3 % faster
+  bool auto_streams = false, split_tuned = false, split_on = false;
+  float tune_ms_single = 0.f, tune_ms_split = 0.f;
+  int force_schedule = -1;        // dptx_tune_schedule: 0 / 1 while it times a candidate
   int half_batch = 0;             // images per sub-batch region (ceil(max_batch / n_streams))
   size_t half_region = 0;         // bytes of one sub-batch region (n_streams of them fit in one arena plane)
   hipStream_t sub_stream[MAX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
@@ -1316,6 +1321,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
     const char* t = getenv("DPTX_STREAMS");  // experiments: overrides cfg.streams
     const int ns = t ? atoi(t) : cfg->streams;
     e->n_streams = ns == 0 ? 2 : (ns < 1 ? 1 : (ns > dptx_engine::MAX_STREAMS ? dptx_engine::MAX_STREAMS : ns));
+    e->auto_streams = ns == 0;
   }
   e->max_w = max_w;
   e->tok_tap_stride = (size_t)cfg->max_batch * ((size_t)max_h * max_w / 256 + 1) * (size_t)e->dv;
@@ -1543,7 +1549,8 @@ static int run_forward(dptx_handle h, const void* x, int io, void* y, void* y2, 
                        hipStream_t stream) {
   const int C = h->cfg.num_channels;
   const size_t esz = io == DPTX_IO_FP32 ? 4 : 2;  // bytes per element of the caller's buffers
-  const bool split = h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling && !h->calibrating;
+  const bool want_split = h->force_schedule >= 0 ? h->force_schedule == 1 : (!h->auto_streams || (h->split_tuned && h->split_on));
+  const bool split = want_split && h->n_streams >= 2 && batch >= 2 && !h->taps_on && !h->profiling && !h->calibrating;
   // tile selection of the GEMMs (kernels.h gemm_set_cu_share): a sub-batch run shares the chip with the other streams' runs.
   // Measured (profiles/r03_experiments.md, two streams): the 256x256 rule judged against 1 / streams of the chip (the
   // half-batch qkv, proj and fc2 GEMMs then take the ping-pong kernel) -- with the lockstep-epilogue kernel of the first half
@@ -1646,6 +1653,76 @@ int dptx_forward_dual(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y
   DeviceGuard guard(h->cfg.device_id);
   HIPCHK(h, guard.err);
   return run_forward(h, x_dev, x_dtype, y_normal_dev, y_depth_dev, batch, height, width, (hipStream_t)stream);
+}
+
+int dptx_tune_schedule(dptx_handle h, const void* x_dev, int32_t x_dtype, void* y_dev, void* y_depth_dev, int32_t batch,
+                       int32_t height, int32_t width, int32_t reps, void* stream) {
+  if (!h || !x_dev || !y_dev) return DPTX_E_INVALID;
+  if (h->cfg.device_id < 0) return h->fail(DPTX_E_NODEVICE, "dptx_tune_schedule on a host-only handle");
+  if (!h->device_ready) return h->fail(DPTX_E_INVALID, "dptx_tune_schedule before weights were finalized/imported");
+  if ((h->cfg.dual_task != 0) != (y_depth_dev != nullptr)) return h->fail(DPTX_E_INVALID, "dptx_tune_schedule: y_depth_dev is for dual-task handles");
+  if (!h->auto_streams || h->n_streams < 2 || batch < 2) return DPTX_OK;   // nothing to choose
+  if (reps < 1) reps = 2;
+  DeviceGuard guard(h->cfg.device_id);
+  HIPCHK(h, guard.err);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(h, hipEventCreate(&e0));
+  HIPCHK(h, hipEventCreate(&e1));
+  struct Cleanup { dptx_handle h; hipEvent_t a, b; ~Cleanup() { h->force_schedule = -1; (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } cleanup{h, e0, e1};
+  float ms[2] = {0.f, 0.f};
+  auto fwd = [&]() {
+    return h->cfg.dual_task ? dptx_forward_dual(h, x_dev, x_dtype, y_dev, y_depth_dev, batch, height, width, stream)
+                            : dptx_forward_hw(h, x_dev, x_dtype, y_dev, batch, height, width, stream);
+  };
+  for (int cand = 0; cand < 2; ++cand) {
+    h->force_schedule = cand;
+    int rc = fwd();   // untimed: first-use costs (kernel attributes, stream wake-up)
+    if (rc != DPTX_OK) return rc;
+    HIPCHK(h, hipEventRecord(e0, (hipStream_t)stream));
+    for (int r = 0; r < reps; ++r) {
+      rc = fwd();
+      if (rc != DPTX_OK) return rc;
+    }
+    HIPCHK(h, hipEventRecord(e1, (hipStream_t)stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    HIPCHK(h, hipEventElapsedTime(&ms[cand], e0, e1));
+    ms[cand] /= (float)reps;
+  }
+  h->tune_ms_single = ms[0];
+  h->tune_ms_split = ms[1];
+  h->split_on = ms[1] < 0.97f * ms[0];   // the two-stream schedule has to EARN its place: ties go to the simpler one
+  h->split_tuned = true;
+  return DPTX_OK;
+}
+
+int dptx_schedule_info(dptx_handle h, int32_t* split, int32_t* tuned, float* ms_single, float* ms_split) {
+  if (!h) return DPTX_E_INVALID;
+  if (split) *split = h->auto_streams ? (int32_t)(h->split_tuned && h->split_on) : (int32_t)(h->n_streams >= 2);
+  if (tuned) *tuned = (int32_t)(h->auto_streams && h->split_tuned);
+  if (ms_single) *ms_single = h->tune_ms_single;
+  if (ms_split) *ms_split = h->tune_ms_split;
+  return DPTX_OK;
+}
+
+int dptx_probe_stream_overlap(int32_t device_id, void* stream_a, void* stream_b, int32_t spin_us, float* ratio) {
+  if (!ratio || device_id < 0) return DPTX_E_INVALID;
+  DeviceGuard guard(device_id);
+  if (guard.err != hipSuccess) return DPTX_E_HIP;
+  hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+  const long long ticks = (long long)(spin_us > 0 ? spin_us : 2000) * 100;   // s_memrealtime: 100 MHz
+  auto run = [&](bool both, double& sec) -> bool {
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (launch_spin(ticks, a) != hipSuccess) return false;
+    if (both && launch_spin(ticks, b) != hipSuccess) return false;
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+  };
+  double warm = 0, alone = 0, pair = 0;
+  if (!run(true, warm) || !run(false, alone) || !run(true, pair) || alone <= 0) return DPTX_E_HIP;
+  *ratio = (float)(pair / alone);
+  return DPTX_OK;
 }
 
 int dptx_set_layer_precision(dptx_handle h, const char* conv_weight_key, int32_t mfmas) {

@@ -139,6 +139,7 @@ hipError_t launch_nonfinite_scan(int mode, const void* X, size_t n, unsigned* fl
 
 // debug: *out += 64-bit sum of the 32-bit words of [p, p + bytes)
 hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t stream);
+hipError_t launch_spin(long long ticks_100mhz, hipStream_t stream);   // one sleeping wave (dptx_probe_stream_overlap)
 
 // y NCHW fp32 [B,Cout,HW] = act( W[Cout][32] * x[B*HW,32] + b ),  Cout <= 4
 hipError_t launch_head_out(int mode, const void* X, const float* w, const float* b, void* y, int io, int B, int HW,

@@ -136,6 +136,17 @@ __global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restric
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(out, s);
 }
+// dptx_probe_stream_overlap: one wave that does nothing for `ticks` ticks of the 100 MHz wall clock (s_memrealtime) -- long
+// enough to dominate launch overheads, small enough (one wave, asleep) not to disturb anything that shares the chip
+__global__ __launch_bounds__(64) void spin_kernel(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+hipError_t launch_spin(long long ticks, hipStream_t stream) {
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
+  return hipGetLastError();
+}
+
 hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t stream) {
   const size_t n32 = bytes / 4;
   if (n32 == 0) return hipSuccess;

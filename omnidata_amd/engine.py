@@ -55,6 +55,9 @@ ABI = [
     ("dptx_forward_hw", C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_forward_dual", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_set_layer_precision", C.c_int, [_vp, C.c_char_p, _i32]),
+    ("dptx_tune_schedule", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    ("dptx_schedule_info", C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _f32p, _f32p]),
+    ("dptx_probe_stream_overlap", C.c_int, [_i32, _vp, _vp, _i32, _f32p]),
     ("dptx_calibrate_fp8", C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_fp8_get_calibration", C.c_int, [_vp, _f32p, _f32p, _i32]),
     ("dptx_share_packed", C.c_int, [_vp, _vp]),
@@ -164,6 +167,16 @@ def _stream(device=None) -> int:
 IO_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # include/dptx.h DPTX_IO_*
 
 
+def probe_stream_overlap(stream_a, stream_b, device_index: int = 0, spin_us: int = 2000) -> float:
+    """t(both streams busy) / t(one stream busy) for a sleeping one-wave kernel (include/dptx.h dptx_probe_stream_overlap):
+    ~1.0 = the two torch streams run concurrently, ~2.0 = the runtime serialises them (one hardware queue).  Blocks."""
+    r = C.c_float(0)
+    rc = load_library().dptx_probe_stream_overlap(int(device_index), stream_a.cuda_stream, stream_b.cuda_stream, int(spin_us), C.byref(r))
+    if rc != 0:
+        raise RuntimeError(f"dptx_probe_stream_overlap failed: {ERRORS.get(rc, rc)}")
+    return float(r.value)
+
+
 def _check_out(out: torch.Tensor, shape, device, dtype=torch.float32):
     if (out.dtype != dtype or not out.is_contiguous() or out.device != device or tuple(out.shape) != tuple(shape)):
         raise ValueError(f"out must be a contiguous {dtype} tensor of shape {tuple(shape)} on {device}, got "
@@ -196,6 +209,9 @@ class Engine:
         # packed weights, so every handle that is meant to compute what this one computes (ForwardPipeline.from_engine, an
         # engine rebuilt for a larger input) replays them
         self.layer_precision: Dict[str, int] = {}
+        # streams = 0 (the default): the intra-forward schedule is MEASURED at the first forward of at least AUTO_TUNE_MIN_BATCH
+        # images (include/dptx.h dptx_tune_schedule; a few extra forwards and one host synchronisation, once per handle)
+        self._schedule_tuned = bool(streams) or bool(os.environ.get("DPTX_STREAMS")) or device_id is None
         self.dtype = dtype
         self.backbone = backbone
         self.h = _vp()
@@ -286,6 +302,23 @@ class Engine:
         self.import_packed(blob.to(f"cuda:{self.cfg.device_id}"))
 
     # ---- compute
+    AUTO_TUNE_MIN_BATCH = 8
+
+    def tune_schedule(self, x: torch.Tensor, out: torch.Tensor, out_depth: Optional[torch.Tensor] = None, reps: int = 2) -> dict:
+        """Times this batch's forward under both intra-forward schedules and keeps the faster one (include/dptx.h
+        dptx_tune_schedule); blocks until done.  `out` (and `out_depth`) receive a valid result."""
+        B, _, H, W = x.shape
+        self._check(self.lib.dptx_tune_schedule(self.h, x.data_ptr(), IO_DTYPES[x.dtype], out.data_ptr(), _ptr(out_depth), B, H, W,
+                                                int(reps), _stream(x.device)), "tune_schedule")
+        self._schedule_tuned = True
+        return self.schedule_info()
+
+    def schedule_info(self) -> dict:
+        """{'split': two half-batches on two internal streams?, 'tuned': measured?, 'ms_single', 'ms_split'}"""
+        sp, tu, a, b = C.c_int32(0), C.c_int32(0), C.c_float(0), C.c_float(0)
+        self._check(self.lib.dptx_schedule_info(self.h, C.byref(sp), C.byref(tu), C.byref(a), C.byref(b)), "schedule_info")
+        return {"split": bool(sp.value), "tuned": bool(tu.value), "ms_single": round(a.value, 4), "ms_split": round(b.value, 4)}
+
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("dptx forward needs a CUDA(HIP) tensor; there is no CPU fallback")
@@ -301,6 +334,8 @@ class Engine:
             out = torch.empty(B, self.cfg.num_channels, H, W, dtype=x.dtype, device=x.device)
         else:
             _check_out(out, (B, self.cfg.num_channels, H, W), x.device, x.dtype)
+        if not self._schedule_tuned and B >= self.AUTO_TUNE_MIN_BATCH:
+            self.tune_schedule(x, out)
         self._check(self.lib.dptx_forward_hw(self.h, x.data_ptr(), IO_DTYPES[x.dtype], out.data_ptr(), B, H, W,
                                              _stream(x.device)), "forward")
         return out
@@ -326,6 +361,8 @@ class Engine:
             out_depth = torch.empty(B, 1, H, W, dtype=x.dtype, device=x.device)
         else:
             _check_out(out_depth, (B, 1, H, W), x.device, x.dtype)
+        if not self._schedule_tuned and B >= self.AUTO_TUNE_MIN_BATCH:
+            self.tune_schedule(x, out_normal, out_depth)
         self._check(self.lib.dptx_forward_dual(self.h, x.data_ptr(), IO_DTYPES[x.dtype], out_normal.data_ptr(), out_depth.data_ptr(), B, H, W,
                                                _stream(x.device)), "forward_dual")
         return out_normal, out_depth

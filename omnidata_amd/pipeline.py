@@ -27,7 +27,7 @@ from typing import Iterable, Iterator, List, Optional
 
 import torch
 
-from .engine import IO_DTYPES, Engine
+from .engine import IO_DTYPES, Engine, probe_stream_overlap
 
 
 class Ticket:
@@ -55,9 +55,10 @@ class ForwardPipeline:
     """`depth` Engine handles on `depth` streams behind one submit / wait interface; see the module docstring.
 
     Constructor arguments are Engine's (num_channels, max_batch, dtype, device_id, dual, x3_groups, backbone, flags, max_hw ...);
-    `inner_streams` is the internal stream count of each handle (1: the measured optimum with two forwards in flight)."""
+    `inner_streams` is the internal stream count of each handle (1: the measured optimum with two forwards in flight);
+    `check_overlap`: probe at construction that the slot streams really run concurrently (`overlap_ratio`; see ensure_overlap)."""
 
-    def __init__(self, depth: int = 2, inner_streams: int = 1, **engine_kwargs):
+    def __init__(self, depth: int = 2, inner_streams: int = 1, check_overlap: bool = True, overlap_retries: int = 3, **engine_kwargs):
         if depth < 1:
             raise ValueError("depth >= 1")
         if engine_kwargs.get("device_id", 0) is None:
@@ -78,8 +79,41 @@ class ForwardPipeline:
             least, greatest = 0, -1
         levels = list(range(least, greatest - 1, -1)) or [0]
         self.streams = [torch.cuda.Stream(device=self.device, priority=levels[i % len(levels)]) for i in range(self.depth)]
+        self._levels = levels
         self._next = 0
         self.dual = bool(engine_kwargs.get("dual", False))
+        # Does the overlap this class exists for actually happen?  (it silently depended on what the runtime did
+        # with the streams.)  Neighbouring slots are probed with a sleeping one-wave kernel; a pair that serialises gets fresh
+        # streams (other priority order first) up to `overlap_retries` times, and what is left is reported, not hidden.
+        self.overlap_ratio: Optional[float] = None
+        if check_overlap and self.depth >= 2:
+            self.overlap_ratio = self.ensure_overlap(overlap_retries)
+
+    SERIALISED = 1.5   # t(both) / t(alone) above this: the two streams did not run concurrently
+
+    def measure_overlap(self) -> float:
+        """Worst t(both) / t(alone) over neighbouring slot streams: ~1.0 concurrent, ~2.0 serialised."""
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        return max(probe_stream_overlap(self.streams[i], self.streams[(i + 1) % self.depth], idx) for i in range(self.depth - 1))
+
+    def ensure_overlap(self, retries: int = 3) -> float:
+        ratio = self.measure_overlap()
+        for attempt in range(retries):
+            if ratio < self.SERIALISED:
+                break
+            # new streams; the runtime hands out the least-referenced hardware queue of a priority level, so both a new stream
+            # of the same level and the other level's pool are worth trying
+            old = self.streams
+            self.streams = [torch.cuda.Stream(device=self.device, priority=self._levels[(i + attempt + 1) % len(self._levels)])
+                            for i in range(self.depth)]
+            ratio = self.measure_overlap()
+            del old
+        if ratio >= self.SERIALISED:
+            import warnings
+            warnings.warn(f"omnidata_amd.ForwardPipeline: the slot streams do not run concurrently on this device (probe ratio "
+                          f"{ratio:.2f}, 2.0 = fully serialised) -- forwards in flight will execute one after the other; "
+                          f"throughput is that of single forwards.  (Too many streams alive in this process share the hardware queues.)")
+        return ratio
 
     @classmethod
     def from_engine(cls, owner: Engine, depth: int = 2, inner_streams: int = 1, max_batch: Optional[int] = None) -> "ForwardPipeline":

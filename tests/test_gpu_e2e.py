@@ -190,10 +190,10 @@ def test_fused_head_equals_unfused(dtype):
     xg = x.to(DEV)
     y_fused = model(xg).clone()
     eng = model.engine
-    launches_fused = eng.info()[0]  # two half-batch runs on two streams
+    launches_fused = eng.info()[0]  # one run over the whole batch (streams = 0: one stream until a schedule has been measured)
     eng.enable_taps(True)
-    y_unfused = model(xg).clone()      # taps: one run over the whole batch, three launches instead of one for the head tail
-    assert launches_fused == 2 * (eng.info()[0] - 2)
+    y_unfused = model(xg).clone()      # taps: three launches instead of one for the head tail
+    assert launches_fused == eng.info()[0] - 2
     h1 = eng.tap("h1").double()        # [B,32,384,384], the 16-bit values the unfused 1x1 projection read
     eng.enable_taps(False)
     mant = 8 if dtype == "bf16" else 11   # significand bits
@@ -236,6 +236,39 @@ def test_two_stream_split_is_bit_identical():
         assert (n > 300) == (streams == 2)   # 2 x 199 launches on two streams, 199 on one
         eng.close()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_measured_schedule_choice_is_bit_identical_and_reported():
+    """dptx_config.streams = 0 (the default, round 6): one stream until dptx_tune_schedule has timed both intra-forward schedules
+    on the caller's batch; the two-half schedule is kept only if it was >= 3 % faster; either way the bits are the same.
+    Engine.forward tunes by itself at the first batch of >= 8 images; explicit streams are never overridden."""
+    from omnidata_amd.engine import Engine
+    sd = random_state_dict(0, 3)
+    x = synthetic_input(9, 8, "normal").to(DEV)
+    ref = Engine(num_channels=3, max_batch=8, dtype="bf16", device_id=0, streams=1)
+    ref.load_state_dict(sd)
+    y_ref = ref.forward(x).clone()
+    assert ref.schedule_info() == {"split": False, "tuned": False, "ms_single": 0.0, "ms_split": 0.0}
+    eng = Engine(num_channels=3, max_batch=8, dtype="bf16", device_id=0)     # streams = 0
+    eng.share_weights_from(ref)
+    assert eng.schedule_info()["tuned"] is False and eng.schedule_info()["split"] is False
+    y_small = eng.forward(x[:3]).clone()                                      # below AUTO_TUNE_MIN_BATCH: no measurement
+    assert eng.schedule_info()["tuned"] is False and torch.equal(y_small, y_ref[:3]) and eng.info()[0] < 300
+    y = eng.forward(x).clone()                                                # first big batch: measured, then run
+    info = eng.schedule_info()
+    print(f"\nmeasured schedule: {info}")
+    assert info["tuned"] and info["ms_single"] > 0 and info["ms_split"] > 0
+    assert info["split"] == (info["ms_split"] < 0.97 * info["ms_single"])
+    assert torch.equal(y, y_ref)
+    for _ in range(4):
+        assert torch.equal(eng.forward(x), y_ref)
+    assert (eng.info()[0] > 300) == info["split"]                             # the chosen schedule is the one that runs
+    two = Engine(num_channels=3, max_batch=8, dtype="bf16", device_id=0, streams=2)   # explicit: never overridden
+    two.share_weights_from(ref)
+    assert torch.equal(two.forward(x), y_ref) and two.info()[0] > 300
+    assert two.schedule_info()["split"] is True and two.schedule_info()["tuned"] is False
+    for e in (two, eng, ref):
+        e.close()
 
 
 def test_packed_blob_cache_roundtrip(tmp_path):

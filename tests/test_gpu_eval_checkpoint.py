@@ -1,0 +1,75 @@
+"""tools/eval_checkpoint.py on a SYNTHETIC Lightning checkpoint -- the published ones
+cannot be fetched here: the harness must load the file the way demo.py:62-72 does, report the fp16 range flag and the stage-tap
+maxima (what decides mixed vs bf16x3 on a real checkpoint), compare the parity mode with the reference-grade one, and produce the
+paper's metrics from ground-truth files.  pytest -m gpu."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from omnidata_amd.weights import random_state_dict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _images(d, n=3):
+    rng = np.random.default_rng(0)
+    os.makedirs(d, exist_ok=True)
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, (400 + 16 * i, 500, 3), dtype=np.uint8)).save(os.path.join(d, f"im{i}.png"))
+
+
+def test_eval_checkpoint_on_a_synthetic_lightning_ckpt(tmp_path):
+    import eval_checkpoint as ec
+    sd = random_state_dict(0, 3)
+    ckpt = tmp_path / "omnidata_dpt_normal_v2.ckpt"
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}, "epoch": 3}, ckpt)   # Lightning layout, demo.py:65-68
+    img_dir, gt_dir = str(tmp_path / "img"), str(tmp_path / "gt")
+    _images(img_dir)
+    os.makedirs(gt_dir)
+    rng = np.random.default_rng(1)
+    for i in range(2):   # ground truth for two of the three images: normals as [-1,1] vectors (.npy) and as a [0,1] image (.png)
+        n = rng.normal(size=(400 + 16 * i, 500, 3)).astype(np.float32)
+        n /= np.linalg.norm(n, axis=2, keepdims=True)
+        if i == 0:
+            np.save(os.path.join(gt_dir, "im0.npy"), n)
+        else:
+            Image.fromarray(((n + 1) * 127.5).astype(np.uint8)).save(os.path.join(gt_dir, "im1.png"))
+            m = np.zeros(n.shape[:2], np.uint8)
+            m[50:300, 60:400] = 255
+            Image.fromarray(m).save(os.path.join(gt_dir, "im1_mask.png"))
+    out = tmp_path / "report.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eval_checkpoint.py"), "--task", "normal", "--ckpt", str(ckpt),
+                        "--images", img_dir, "--gt", gt_dir, "--dtypes", "bf16x3,mixed", "--batch", "2", "--out", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(out.read_text())
+    assert rep["images"] == 3 and rep["tensors"] == len(sd)
+    ref, par = rep["dtypes"]["bf16x3"], rep["dtypes"]["mixed"]
+    assert ref["range_flag_overflow"] is None and par["range_flag_overflow"] is False          # healthy weights stay in range
+    assert set(ec.TAPS) <= set(par["stage_tap_max_abs"]) and all(v["finite"] for v in par["stage_tap_max_abs"].values())
+    assert max(v["max_abs"] for v in par["stage_tap_max_abs"].values()) < 65504
+    assert par["vs_bf16x3"]["meets_1e-3"] and par["vs_bf16x3"]["max_abs"] < 1e-3               # parity mode == reference-grade mode
+    for e in (ref, par):
+        assert e["metrics_images"] == 2 and {"ang_error_mean", "ang_error_median", "percentage_within_11.25_degrees"} <= set(e["metrics"])
+        assert 40 < e["metrics"]["ang_error_mean"] < 140                                       # random normals vs random weights
+    # a checkpoint whose activations leave the fp16 range: the flag says so (ReLU homogeneity: same function, 1e8 x larger decoder
+    # activations, as in test_default_model_leaves_fp16_planes_when_they_overflow), bf16x3 stays finite
+    big = {k: v.clone() for k, v in sd.items()}
+    for k in big:
+        if (k.startswith("scratch.layer") and k.endswith("_rn.weight")) or (k.startswith("scratch.refinenet") and k.endswith(".bias")):
+            big[k] *= 1.0e8
+    big["scratch.output_conv.0.weight"] /= 1.0e8
+    raw = tmp_path / "big.pt"
+    torch.save(big, raw)                                                                       # raw state_dict, demo.py:69-70
+    rep2 = ec.evaluate("normal", str(raw), [os.path.join(img_dir, "im0.png")], None, ("bf16x3", "mixed"), 1)
+    assert rep2["dtypes"]["mixed"]["range_flag_overflow"] is True
+    assert rep2["dtypes"]["bf16x3"]["output"]["finite"] and rep2["dtypes"]["mixed"]["stage_tap_max_abs"]["p1"]["max_abs"] > 65504 or \
+        not rep2["dtypes"]["mixed"]["stage_tap_max_abs"]["p1"]["finite"]

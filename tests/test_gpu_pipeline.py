@@ -187,3 +187,26 @@ def test_model_forward_pipelined_caches_chunks_and_matches_model():
     model.load_state_dict(random_state_dict(1, 3))                                       # new weights: the engine and its pipeline go
     got3 = list(model.forward_pipelined(xs[:1], depth=2))
     assert model._pipe is not pipe and not torch.equal(got3[0], refs[0]) and torch.equal(got3[0], model(xs[0]))
+
+
+def test_stream_overlap_probe_tells_concurrent_from_serialised():
+    """nothing used to check that the pipeline's streams overlap.  dptx_probe_stream_overlap on ONE stream twice
+    (the forced-serial case: two launches on one queue) must read ~2, on the pipeline's two slot streams ~1; ForwardPipeline
+    records the ratio it found and warns when it cannot get below 1.5."""
+    from omnidata_amd.engine import probe_stream_overlap
+    s = torch.cuda.Stream()
+    serial = probe_stream_overlap(s, s, 0)
+    assert 1.7 < serial < 2.4, serial                      # same stream = same queue: one after the other
+    pipe = ForwardPipeline(depth=2, num_channels=3, max_batch=2, dtype="bf16", device_id=0)
+    print(f"\nprobe: one stream twice {serial:.2f}, pipeline slots {pipe.overlap_ratio:.2f}")
+    assert pipe.overlap_ratio is not None and pipe.overlap_ratio < ForwardPipeline.SERIALISED
+    assert abs(pipe.measure_overlap() - pipe.overlap_ratio) < 0.4
+    # a pipeline whose two slots are the SAME stream serialises, and says so
+    import warnings
+    pipe.streams = [s, s]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        pipe._levels = [0]
+        r = ForwardPipeline.ensure_overlap(pipe, retries=0)
+    assert r > 1.7 and any("do not run concurrently" in str(m.message) for m in w)
+    pipe.close()

@@ -499,3 +499,62 @@ def test_pipeline_has_no_cpu_fallback_and_ticket_api():
         model = DPTDepthModel(num_channels=3, dtype="bf16", max_batch=2)
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             list(model.forward_pipelined([torch.rand(1, 3, 384, 384)]))
+
+
+def test_gpu_telemetry_reads_a_sysfs_tree(tmp_path):
+    """omnidata_amd/telemetry.py (bench.py's clock / power attribution) against a fake amdgpu sysfs tree: card
+    selection by PCI address, hwmon files, the sampling thread, and 'not available' instead of an error when nothing is there."""
+    import time
+    from omnidata_amd.telemetry import GpuTelemetry, find_card
+    root = tmp_path / "drm"
+    for i, pci in enumerate(("0000:05:00.0", "0000:c1:00.0")):
+        real = tmp_path / "devices" / pci
+        hw = real / "hwmon" / "hwmon3"
+        hw.mkdir(parents=True)
+        (real / "driver").symlink_to(tmp_path / "drivers" / "amdgpu")
+        (hw / "freq1_input").write_text(f"{1900 + 100 * i}000000\n")
+        (hw / "power1_average").write_text("1000000000\n")
+        (hw / "power1_cap").write_text("1400000000\n")
+        (hw / "temp1_input").write_text("55000\n")
+        (hw / "temp1_label").write_text("edge\n")
+        (real / "gpu_busy_percent").write_text("97\n")
+        (root / f"card{i}").mkdir(parents=True)
+        (root / f"card{i}" / "device").symlink_to(real)
+    (tmp_path / "drivers" / "amdgpu").mkdir(parents=True)
+    assert find_card("0000:C1:00.0", str(root)).endswith("card1/device")
+    assert find_card(None, str(root)) is None            # two cards and no address: no guessing
+    t = GpuTelemetry(0, interval_s=0.005, card_dir=find_card("0000:c1:00.0", str(root)))
+    assert t.available and t.read_once()["sclk_mhz"] == 2000.0
+    with t:
+        time.sleep(0.05)
+    s = t.summary()
+    assert s["available"] and s["samples"] >= 3 and s["sclk_mhz"] == {"mean": 2000.0, "min": 2000.0, "max": 2000.0}
+    assert s["power_w"]["mean"] == 1000.0 and s["power_cap_w"] == 1400.0 and s["temp_edge_c"]["max"] == 55.0 and s["busy_pct"]["mean"] == 97.0
+    none = GpuTelemetry(0, card_dir=str(tmp_path / "nothing"))
+    assert not none.available and none.start().stop().summary()["available"] is False
+
+
+def test_eval_checkpoint_tool_host_side(tmp_path):
+    """tools/eval_checkpoint.py without a GPU: the reference CLI's path error (demo.py:161-163), ground-truth loading in both
+    conventions with the input's geometry, and no CPU fallback for the forward."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import eval_checkpoint as ec
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eval_checkpoint.py"), "--task", "normal", "--ckpt", "x.ckpt",
+                        "--images", str(tmp_path / "missing")], capture_output=True, text=True)
+    assert r.returncode == 1 and "invalid file path!" in r.stdout
+    n = np.zeros((400, 600, 3), np.float32)
+    n[..., 2] = -1.0
+    np.save(tmp_path / "a.npy", n)                                      # [-1,1] vectors -> [0,1] image convention
+    m = np.zeros((400, 600), np.uint8)
+    m[:, :300] = 255
+    Image.fromarray(m).save(tmp_path / "a_mask.png")
+    tgt, msk = ec.load_gt(str(tmp_path), "a", "normal")
+    assert tuple(tgt.shape) == (3, 384, 384) and tuple(msk.shape) == (1, 384, 384)
+    assert torch.allclose(tgt[2], torch.zeros(384, 384)) and torch.allclose(tgt[0], torch.full((384, 384), 0.5))
+    assert msk[0, :, :100].all() and not msk[0, :, 300:].any()        # 600 -> 576 wide, centre crop keeps 96..480: mask edge at 192
+    assert ec.load_gt(str(tmp_path), "nope", "normal") is None
+    if not torch.cuda.is_available():
+        Image.fromarray(np.zeros((384, 384, 3), np.uint8)).save(tmp_path / "i.png")
+        torch.save({"state_dict": {}}, tmp_path / "c.ckpt")
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            ec.evaluate("normal", str(tmp_path / "c.ckpt"), [str(tmp_path / "i.png")])
