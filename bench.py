@@ -57,6 +57,18 @@ def spawn_command(n_gpus, argv, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def rank_cpu_set(local_rank, world, cpus):
+    """The host cores of one rank: the process's allowed CPUs split into `world` contiguous shares (remainder to the low ranks).
+    Eight Python hosts on one node otherwise migrate over all cores and fight for them while they enqueue ~200 launches per
+    forward each; a share per rank keeps every rank's launch thread where its caches are."""
+    cpus = sorted(cpus)
+    if world <= 1 or len(cpus) < world:
+        return cpus
+    base, rem = divmod(len(cpus), world)
+    lo = local_rank * base + min(local_rank, rem)
+    return cpus[lo: lo + base + (1 if local_rank < rem else 0)]
+
+
 FAMILY_KERNELS = ("gemm_glds_kernel", "gemm_pp_kernel", "gemm_pp2_kernel", "gemm_reg_kernel", "stem_conv_kernel", "head_tail_kernel",
                   "head_tail_x3_kernel")
 
@@ -194,6 +206,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; the line would "
                          f"report the wrong n_gpus -- pass --gpus {world} (or launch {args.gpus} ranks)")
+    # one share of the host's cores per rank (N > 1): see rank_cpu_set
+    affinity = None
+    if world > 1 and hasattr(os, "sched_setaffinity"):
+        try:
+            mine = rank_cpu_set(local_rank, world, os.sched_getaffinity(0))
+            os.sched_setaffinity(0, mine)
+            affinity = [min(mine), max(mine), len(mine)]
+        except OSError:
+            affinity = None
     if args.rendezvous_check:
         import torch.distributed as dist
         seen = 1
@@ -203,8 +224,16 @@ def main():
             t = torch.ones(1, dtype=torch.int64)
             dist.all_reduce(t)
             seen = int(t.item())
+            ncpu = torch.tensor([len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0], dtype=torch.int64)
+            lo = ncpu.clone()
+            dist.all_reduce(ncpu)                         # disjoint shares add up to the cores the launcher had
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.barrier()
             dist.destroy_process_group()
+            if rank == 0:
+                emit({"n_gpus": world, "ranks_seen": seen, "rendezvous_check": True, "cpus_pinned_total": int(ncpu.item()),
+                      "cpus_per_rank_min": int(lo.item())})
+            return
         if rank == 0:
             emit({"n_gpus": world, "ranks_seen": seen, "rendezvous_check": True})
         return
@@ -317,11 +346,22 @@ def main():
             pipe.close()
         return dt_, ok_
 
+    # n forwards in flight need n activation arenas next to the model's own (ForwardPipeline.from_engine): refuse what does not
+    # fit instead of dying in hipMalloc halfway through the run
+    def pipeline_fits(n):
+        free, _total = torch.cuda.mem_get_info(device)
+        arena = eng.workspace_bytes - eng.packed_bytes
+        return n * arena + (256 << 20) <= free, n * arena, free
+    if args.inflight > 1:
+        ok_fit, need_b, free_b = pipeline_fits(args.inflight)
+        if not ok_fit:
+            raise SystemExit(f"bench.py: --inflight {args.inflight} needs {need_b / 2**30:.1f} GiB of activation arenas on top of what is "
+                             f"allocated, {free_b / 2**30:.1f} GiB of HBM are free on {device}: lower --inflight or --batch")
     # The other schedule first (rank 0, N = 1), the headline last: both schedules on THIS box in THIS process.  (First, so
     # that the engine's internal streams exist before the pipeline's: measured the other way round -- lease r5l3 -- the
     # one-forward-at-a-time loop ran at 1993 instead of ~2600 images/s; HIP maps streams onto a small number of hardware queues.)
     schedule_ab = None
-    if rank == 0 and world == 1 and not args.no_schedule_ab:
+    if rank == 0 and world == 1 and not args.no_schedule_ab and (args.inflight > 1 or pipeline_fits(2)[0]):
         other = 1 if args.inflight > 1 else 2
         dt_o, _ = timed(eng, other, args.steps, args.warmup, x, y, dual, y2 if dual else None, tag=f"inflight{other}")
         schedule_ab = {"inflight": other, "value": round(args.batch * args.steps / dt_o, 2), "unit": "images/s",
@@ -579,6 +619,7 @@ def main():
                        "parallelism": f"replicas x{world} (no collective in the loop)",
                        "ranks_seen": ranks_seen, "rank_devices": rank_devices, "dist_backend": args.dist_backend if (world > 1 or args.dist_selftest) else None,
                        "per_rank_images_per_s": {"min": round(min(per_rank), 2), "max": round(max(per_rank), 2)},
+                       "rank0_cpu_affinity": affinity,   # [first, last, count] of this rank's share of the host cores (N > 1)
                        "weight_broadcast": getattr(eng, "replication", None),
                        "schedule": (f"{args.inflight} forwards of {args.batch} images in flight per GPU: {args.inflight} handles x 1 stream, one "
                                     f"shared copy of the weights (omnidata_amd/pipeline.py); batch latency ~ {args.inflight} x ms_per_step"

@@ -8,8 +8,9 @@ alexsax/omnidata_models):
 
 Normal models take 384x384 RGB in [0,1], depth models in [-1,1].  The returned nn.Module runs
 its forward in libdptx.so on an MI355X.  Engine kwargs: max_batch, dtype -- default 'mixed', the mode that
-matches the reference's fp32 forward within 1e-3; 'fp16x3' / 'bf16x3' are reference-grade, 'bf16' / 'fp16' / 'fp8' are
-~2x faster single-pass throughput modes that do NOT meet 1e-3 (omnidata_amd/model.py DPTDepthModel).
+matches the reference's fp32 forward within 1e-3; 'fp16x3' / 'bf16x3' are reference-grade, 'bf16' / 'fp16' are
+~1.6x faster single-pass throughput modes that do NOT meet 1e-3 ('fp8': a lossy decoder variant of 'bf16' that is not faster
+than it on the boxes measured -- omnidata_amd/model.py DPTDepthModel).
 Inputs of other sizes (H, W multiples of 32) are accepted as the reference accepts them (resized pos_embed).
 `dual_dpt_hybrid_384` (not in the reference) returns normals and depth from one encoder pass.
 """

@@ -13,19 +13,18 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdptx.so")
 SOURCES = ["gemm.hip", "gemm_fp16.hip", "gemm_fp16e.hip", "gemm_x3.hip", "gemm_x2.hip", "gemm_fp8.hip", "attention.hip", "norm.hip", "misc.hip", "stem.hip", "head.hip", "prepost.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_impl.h", os.path.join("..", "..", "include", "dptx.h")]
-# Per-source compiler flags.  norm.hip / misc.hip (HBM-bound glue) are built without packed fp32 arithmetic: hipcc's SLP
-# vectoriser otherwise emits v_pk_add_f32 / v_pk_fma_f32 with op_sel swizzles there (low lane reading a high dword), the
-# form that misbehaved in the GEMM epilogue next to a co-resident kernel (csrc/gemm_impl.h ln_fold_fma); these
-# kernels do not need the packed rate.  tests/test_build_quality.py checks every unit's ISA for that form.
-SOURCE_FLAGS = {"norm.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
-                "misc.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
-# A/B of VERDICT r5 W11 (round 6): DPTX_GEMM_NOPK=1 builds the GEMM translation units without packed fp32 arithmetic as well
-# (the suspected-erratum form then cannot be emitted there at all, whatever a toolchain bump does to the SLP vectoriser)
+# Per-source compiler flags.  Every kernel source except attention / stem / head / prepost is built WITHOUT packed fp32 arithmetic.
+# norm.hip / misc.hip (round 4): hipcc's SLP vectoriser emitted v_pk_add_f32 / v_pk_fma_f32 with op_sel swizzles there (low lane
+# reading a high dword), the form that returned a zero product in the GEMM epilogue next to a co-resident kernel (a suspected
+# erratum: profiles/history.md section 10).  The six GEMM translation units (round 6): the fix there was an
+# empty asm that keeps the vectoriser from pairing the LayerNorm-fold fmas -- regex-deep, a toolchain bump away from silently
+# wrong results; with the target feature off the form cannot be emitted at all.  Measured neutral end to end (three alternating
+# same-box pairs: 2625 / 2627 / 2625 vs 2623 / 2630 / 2637 images/s, profiles/r06_ab_gemm_nopk.txt).
+# tests/test_build_quality.py checks every unit's ISA for the form.
 _NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-if os.environ.get("DPTX_GEMM_NOPK") == "1":
-    for _src in ("gemm.hip", "gemm_fp16.hip", "gemm_fp16e.hip", "gemm_x3.hip", "gemm_x2.hip", "gemm_fp8.hip"):
-        SOURCE_FLAGS[_src] = list(_NOPK)
-EXPERIMENT_HEADERS = [os.path.join("experiments", "gemm_experiments.h"), os.path.join("experiments", "gemm_experiments_dispatch.h")]
+SOURCE_FLAGS = {src: list(_NOPK) for src in ("norm.hip", "misc.hip", "gemm.hip", "gemm_fp16.hip", "gemm_fp16e.hip", "gemm_x3.hip",
+                                             "gemm_x2.hip", "gemm_fp8.hip")}
+EXPERIMENT_HEADERS = []   # (rounds 2-5 kept opt-in experiment kernels under csrc/experiments/; removed in round 6, see git history)
 
 
 def source_hash(extra_flags=()) -> str:
@@ -89,18 +88,26 @@ def _build_locked(force: bool, verbose: bool, suffix: str, objdir: str) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if not force and _newer(o, [s] + hdrs) and not (src == "engine.hip" and old_hash != src_hash):
-            continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + SOURCE_FLAGS.get(src, []) + extra + ["-c", s, "-o", o]
         if src == "engine.hip":
             cmd.insert(-4, f'-DDPTX_SRC_HASH="{src_hash}"')
+        # an object is current only if it is newer than its sources AND was compiled by this very command line (round 6: a
+        # change of SOURCE_FLAGS alone used to leave the old objects in place under a library that carried the new hash)
+        cmd_file = o + ".cmd"
+        same_cmd = os.path.exists(cmd_file) and open(cmd_file).read() == " ".join(cmd)
+        if not force and same_cmd and _newer(o, [s] + hdrs):
+            continue
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, p in procs:
+        if os.path.exists(cmd_file):
+            os.remove(cmd_file)
+        procs.append((src, cmd_file, " ".join(cmd), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, cmd_file, cmd_txt, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        with open(cmd_file, "w") as f:
+            f.write(cmd_txt)
     if force or procs or not _newer(LIB, objs):
         tmp = f"{LIB}.tmp{os.getpid()}"
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs

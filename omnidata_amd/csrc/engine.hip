@@ -1231,14 +1231,10 @@ extern "C" {
 #ifndef DPTX_SRC_HASH
 #define DPTX_SRC_HASH "unknown"
 #endif
-#ifdef DPTX_EXPERIMENTS
-#define DPTX_BUILD_KIND " experiments"
-#else
 #define DPTX_BUILD_KIND ""
-#endif
 // "src=<hash>": sha256 of the sources this binary was built from (omnidata_amd/build.py source_hash); the Python loader
 // compares it with the sources next to the .so and refuses a stale binary
-const char* dptx_version(void) { return "dptx 0.3.0 (gfx950" DPTX_BUILD_KIND ") src=" DPTX_SRC_HASH; }
+const char* dptx_version(void) { return "dptx 0.3.0 (gfx950) src=" DPTX_SRC_HASH; }
 
 void dptx_default_config(dptx_config* cfg) {
   memset(cfg, 0, sizeof *cfg);

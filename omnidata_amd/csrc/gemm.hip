@@ -49,9 +49,6 @@ hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
     return launch_gemm_fp8(p, stream);
   }
   if (p.K % BK != 0 || p.Cin % BK != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 8 != 0) return hipErrorInvalidValue;
-#ifdef DPTX_EXPERIMENTS
-  if (halo_shape(p)) p.k_tap_fast = 1;  // one k order for these shapes, whichever kernel runs them (all modes)
-#endif
   if (mode == MODE_BF16) return p.epi2 ? hipErrorInvalidValue : launch_gemm_16(DT_BF16, p, stream);
   if (mode == MODE_FP16) return p.epi2 ? launch_gemm_fp16e(p, stream) : launch_gemm_16(DT_FP16, p, stream);
   if (mode == MODE_BF16X3) return launch_gemm_x3(DT_BF16, p, stream);

@@ -890,7 +890,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem,
 // its own DMA (vmcnt(0)) at the end of its MFMA slot, i.e. before the barrier in front of the first reader.
 // (Round 2 measured seven variants of this schedule -- third LDS buffer, all DMA on one group, one barrier per k-tile with
 // overlapping MFMA slots, s_setprio, the guide's 8-phase structure, a 256x128 three-stage tile, an LDS-resident conv halo
-// -- all <= 0: profiles/r02_experiments.md; the three that are kernels of their own live in experiments/.)
+// -- all <= 0: profiles/r02_experiments.md; the three that were kernels of their own are in the git history, round 5's tree.)
 // DIRECT: transposed accumulators + epilogue_direct (the launches with a plain epilogue: qkv, fc1, the first convolution of a
 // RCU, layerN_rn, output_conv.0); everything else about the kernel is the same.
 template <int DT, bool RELU_A, int PLE = 1, bool DIRECT = false>
@@ -1331,9 +1331,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pp2_kernel(const GemmParams p) {
 #endif
 }
 
-#ifdef DPTX_EXPERIMENTS
-#include "experiments/gemm_experiments.h"
-#endif
 
 
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_FP32>
@@ -1526,9 +1523,6 @@ static void choose_xcd_grid(const GemmParams& p, int tiles_m, int tiles_n, int& 
   }
 }
 
-#ifdef DPTX_EXPERIMENTS
-#include "experiments/gemm_experiments_dispatch.h"
-#endif
 
 template <int DT, int PL, int BM, int BN, int WM_, int WN_, int PLE = PL, int XT = 3>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
@@ -1541,12 +1535,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
                        p.M < (1 << 23);
   if (PL == 2 && !glds_ok) return hipErrorInvalidValue;  // the 3-pass mode exists only on the direct-to-LDS path
   if constexpr (DT != DT_FP8 && PL == 1 && BM == 256 && BN == 256) {
-#ifdef DPTX_EXPERIMENTS
-    if (experiment_pp() == 2 && DT == DT_BF16 && glds_ok) return launch_ph<DT>(q, tiles, smem, stream);
-    const bool pp = experiment_pp() != 0;  // DPTX_PP=0: the lockstep loop (A/B runs)
-#else
     constexpr bool pp = true;
-#endif
     if (pp && glds_ok) {  // ping-pong schedule of the two wave groups (gemm_pp_kernel)
       // persistent launch: at most 32 blocks per XCD (one per CU), each looping over its XCD slice's tiles; the epilogue's
       // LDS tile sits behind stage 0 (which receives the next tile's first k-tile meanwhile).  DPTX_PERSIST=0: one block per
@@ -1651,12 +1640,6 @@ static hipError_t launch_dt(const GemmParams& p, hipStream_t stream) {
     if (forced == 12864 && p.N % 64 == 0) return launch_cfg<DT, PL, 128, 64, 2, 2, PLE, XT>(p, stream);
     if (forced == 6464 && p.N % 64 == 0) return launch_cfg<DT, PL, 64, 64, 2, 2, PLE, XT>(p, stream);
   }
-#ifdef DPTX_EXPERIMENTS
-  {
-    hipError_t r;
-    if (launch_experiment<DT, PL>(p, forced, m256, stream, r)) return r;
-  }
-#endif
   // 256x256 (8 waves, 1 block/CU; 16-bit modes: the ping-pong kernel): half the DMA issues and 3/4 of the LDS reads per MFMA
   // of the 128x128 tile, but no second block to hide prologue/epilogue and a coarser tail.  Chosen when its estimated
   // efficiency wins: fill of the last round of CUs (256 slots) x 1.5 (the per-tile advantage at K >= 512: 1.25 with round 2's

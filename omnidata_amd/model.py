@@ -148,10 +148,11 @@ class DPTDepthModel(_EngineGuards, BaseModel):
     in ``x3_groups`` ('resnet+embed+reassemble+rn+fusion+head' by default: everything but the ViT blocks) keep hi/lo
     fp16 planes and spend 3 MFMAs per product, the ViT blocks run single-pass fp16 -- within north_star's 1e-3 of the
     fp32 reference forward (profiles/r02_precision_frontier.md, oracle/precision_layers.py).  'fp16x3' / 'bf16x3' run
-    everything with 3 MFMAs (reference-grade, ~1e-5 / ~1e-4).  'bf16' / 'fp16' are single-pass THROUGHPUT modes: ~2x
+    everything with 3 MFMAs (reference-grade, ~1e-5 / ~1e-4).  'bf16' / 'fp16' are single-pass THROUGHPUT modes: ~1.6x
     faster, but ~6e-2 / ~9e-3 max-abs from the reference on the seeded weights -- NOT within 1e-3; 'fp8' additionally
     runs decoder convolutions on e4m3 operands: by default the six that keep it within 2x the bf16 mode's error
-    (oracle/fp8_layers.py), with ``fp8_all=True`` all 19 eligible ones (faster, 7-9 degrees of mean angular error).  ``max_batch`` -- arena size (larger batches are chunked).
+    (oracle/fp8_layers.py) -- measured within 2 % of 'bf16', i.e. NOT a throughput mode (rounds 5-6) -- with ``fp8_all=True``
+    all 19 eligible ones (+9 %, 7-9 degrees of mean angular error).  ``max_batch`` -- arena size (larger batches are chunked).
 
     ``overflow_fallback`` (default on): the fp16 range guard described in ``_EngineGuards`` -- an on-device scan per
     forward, read after the first forward of a set of weights and every 16th one afterwards; falls back to bf16 planes.

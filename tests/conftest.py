@@ -30,14 +30,6 @@ def pytest_collection_modifyitems(session, config, items):
         return (1 if is_self else 0, rank)
 
     items.sort(key=key)  # stable: the order inside a file is kept
-    # the opt-in halo convolution is selected by an environment variable that the library reads once per process: its
-    # parametrized cases run in the child process of test_conv_halo_resident_in_child (DPTX_HALO=1), not in this one
-    if os.environ.get("DPTX_HALO") != "1":
-        keep = [it for it in items if not it.name.startswith("test_conv_halo_resident[")]
-        dropped = [it for it in items if it.name.startswith("test_conv_halo_resident[")]
-        if dropped:
-            config.hook.pytest_deselected(items=dropped)
-            items[:] = keep
 
 
 @pytest.fixture(scope="session")

@@ -99,9 +99,29 @@ def test_bench_gpus_n_starts_n_ranks_in_the_plain_python_form():
     r = _bench(["--gpus", "2", "--rendezvous-check"])
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line == {"n_gpus": 2, "ranks_seen": 2, "rendezvous_check": True}
+    assert {k: line[k] for k in ("n_gpus", "ranks_seen", "rendezvous_check")} == {"n_gpus": 2, "ranks_seen": 2, "rendezvous_check": True}
     r = _bench(["--gpus", "1", "--rendezvous-check"])
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_gpus_8_rendezvous_and_disjoint_cpu_shares():
+    """the driver's 8-GPU form without hardware -- `python bench.py --gpus 8 --rendezvous-check` starts eight
+    ranks that count themselves over gloo, and every rank has pinned itself to its own share of the host cores (disjoint shares
+    add up to the cores the launcher was allowed; on this 8-CPU container that is one core per rank)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    ncpu = len(os.sched_getaffinity(0))
+    r = _bench(["--gpus", "8", "--rendezvous-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8
+    if ncpu >= 8:
+        assert line["cpus_pinned_total"] == ncpu and line["cpus_per_rank_min"] == ncpu // 8
+    # the partition itself: contiguous, disjoint, complete, remainder to the low ranks
+    shares = [bench.rank_cpu_set(r_, 8, range(4, 4 + 19)) for r_ in range(8)]
+    assert sum(shares, []) == list(range(4, 23)) and [len(s_) for s_ in shares] == [3, 3, 3, 2, 2, 2, 2, 2]
+    assert bench.rank_cpu_set(0, 1, range(6)) == list(range(6)) and bench.rank_cpu_set(3, 8, range(4)) == list(range(4))
 
 
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():

@@ -175,7 +175,10 @@ def test_positive_control_packed_fold_shows_the_effect():
 
 if __name__ == "__main__":
     if "--build-control" in sys.argv:
-        env = dict(os.environ, DPTX_CXXFLAGS="-DDPTX_LN_PACKED_FMA", DPTX_LIB_SUFFIX="_lnpk", PYTHONPATH=ROOT)
+        # (round 6: the default build compiles the GEMM units with packed fp32 arithmetic OFF -- omnidata_amd/build.py -- so the
+        #  control has to switch the target feature back on to get round 3's v_pk_fma_f32 form at all; later flags win)
+        env = dict(os.environ, DPTX_CXXFLAGS="-DDPTX_LN_PACKED_FMA -Xclang -target-feature -Xclang +packed-fp32-ops", DPTX_LIB_SUFFIX="_lnpk",
+                   PYTHONPATH=ROOT)
         subprocess.run([sys.executable, "-m", "omnidata_amd.build"], check=True, env=env, cwd=ROOT)
     elif "--control" in sys.argv:
         print(json.dumps(_control_counts()), flush=True)

@@ -98,50 +98,6 @@ def test_conv_implicit_gemm(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("case", [
-    # B, H, W, Cin, Cout, a_relu, act, residual     (3x3, stride 1, pad 1; >= 200 tiles of 8 x 32 pixels x 256 channels)
-    (8, 96, 96, 256, 256, 1, 1, False),    # RCU conv1 at 1/4 resolution
-    (7, 64, 96, 128, 512, 0, 0, True),     # non-square map, two n-tiles, two chunks, residual, odd batch
-    (2, 192, 192, 64, 256, 0, 0, False),   # 1/2-resolution map, one chunk
-])
-def test_conv_halo_resident(dtype, case):
-    """gemm_halo_kernel (LDS-resident input halo; an experiment that is only selected with DPTX_HALO=1, so this test runs
-    it in a child process): against the fp32 convolution, and bit for bit against the implicit-GEMM kernels, which run
-    the same shape when the batch is too small for it (launch_gemm gives both the same k order)."""
-    assert os.environ.get("DPTX_HALO") == "1"  # tests/conftest.py deselects these cases otherwise
-    B, H, W, Cin, Cout, a_relu, act, res = case
-    X = rnd(B, H, W, Cin, dtype=dtype, seed=16)
-    Wt = rnd(Cout, 3, 3, Cin, dtype=dtype, scale=(9 * Cin) ** -0.5, seed=17)
-    bias = torch.randn(Cout, device=DEV) * 0.1
-    R = rnd(B, H, W, Cout, dtype=dtype, seed=18) if res else None
-    ref = conv_ref(X, Wt, bias, 1, 1, 1, H, W, a_relu)
-    if act == 1:
-        ref = F.relu(ref)
-    if res:
-        ref = ref + R.float()
-    got = op_conv(dtype, X, Wt, bias, R, 1, 1, 1, H, W, a_relu, act)
-    assert rel_err(got.float(), ref) < OUT_TOL[dtype]
-    for b in (0, B - 1):  # one image alone: < 200 tiles -> implicit GEMM
-        alone = op_conv(dtype, X[b:b + 1].contiguous(), Wt, bias, R[b:b + 1].contiguous() if res else None, 1, 1, 1, H, W, a_relu, act)
-        assert torch.equal(alone[0], got[b])
-
-
-def test_conv_halo_resident_in_child():
-    """The halo kernel is an EXPERIMENT (csrc/experiments/): it exists only in a library built with
-    DPTX_CXXFLAGS=-DDPTX_EXPERIMENTS DPTX_LIB_SUFFIX=_exp (omnidata_amd/build.py); the default libdptx.so neither contains
-    it nor reads DPTX_HALO.  Skipped unless that library has been built next to the default one."""
-    import subprocess
-    import sys
-    exp_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omnidata_amd", "libdptx_exp.so")
-    if not os.path.exists(exp_lib):
-        pytest.skip("experiments library not built (DPTX_CXXFLAGS=-DDPTX_EXPERIMENTS DPTX_LIB_SUFFIX=_exp python -m omnidata_amd.build)")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__ + "::test_conv_halo_resident"],
-                       env=dict(os.environ, DPTX_HALO="1", DPTX_LIB=exp_lib), capture_output=True, text=True, timeout=900,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,S", [(1, 577), (3, 577), (2, 64), (1, 200), (2, 65), (1, 66), (2, 17), (1, 129)])
 def test_attention(dtype, B, S):
     lib = load_library()
