@@ -108,6 +108,12 @@ inline uint8_t f32_to_e4m3(float f) {
   return sign | (uint8_t)(((e + 7) << 3) | m);
 }
 
+inline float e4m3_to_f32(uint8_t v) {
+  const int e = (v >> 3) & 0xf, m = v & 7;
+  const double a = e == 0 ? std::ldexp((double)m, -9) : std::ldexp(1.0 + m / 8.0, e - 7);
+  return (float)((v & 0x80) ? -a : a);
+}
+
 // --------------------------------------------------------------------------- weight spec
 // R_DECONV: ConvTranspose2d [Cin, Cout, k, k] with kernel == stride, packed as the GEMM operand [(dy*k+dx)*Cout + co][ci];
 // R_DECONV_BIAS: its bias, tiled k*k times so that the GEMM epilogue can add it per column
@@ -127,6 +133,17 @@ void add(std::vector<Spec>& v, const std::string& k, std::vector<int64_t> s, Rol
 // "scratch.*"; both read the one shared encoder "pretrained.*" (SURVEY.md 8d config 5).
 // backbone 0: vitb_rn50_384 (DPT-Hybrid); 1: vitl16_384 (DPT-Large; omnidata_amd/weights.py
 // vitl16_state_dict_spec)
+// fp8 dtype, DPTX_FLAG_FP8_VIT (round 6): per-output-channel inverse scales of the e4m3 copies of qkv / fc1 / fc2 of one block, and
+// the column sums of the DEQUANTISED folded e4m3 weights (the LayerNorm fold's mean term must cancel against what the MFMA
+// actually multiplies)
+void add_vit_fp8(std::vector<Spec>& v, const std::string& p, int D_VIT, int D_MLP) {
+  add(v, p + "attn.qkv.f8scale", {3 * D_VIT}, R_DERIVED);
+  add(v, p + "mlp.fc1.f8scale", {D_MLP}, R_DERIVED);
+  add(v, p + "mlp.fc2.f8scale", {D_VIT}, R_DERIVED);
+  add(v, p + "attn.qkv.lnsum8", {3 * D_VIT}, R_DERIVED);
+  add(v, p + "mlp.fc1.lnsum8", {D_MLP}, R_DERIVED);
+}
+
 std::vector<Spec> build_spec(int C, bool dual, int backbone) {
   std::vector<Spec> v;
   const std::string vp = "pretrained.model.";
@@ -152,6 +169,7 @@ std::vector<Spec> build_spec(int C, bool dual, int backbone) {
       add(v, p + "mlp.fc2.bias", {D_VIT}, R_VEC);
       add(v, p + "attn.qkv.lnsum", {3 * D_VIT}, R_DERIVED);
       add(v, p + "mlp.fc1.lnsum", {D_MLP}, R_DERIVED);
+      add_vit_fp8(v, p, D_VIT, D_MLP);
     }
     add(v, vp + "norm.weight", {D_VIT}, R_UNUSED);
     add(v, vp + "norm.bias", {D_VIT}, R_UNUSED);
@@ -216,6 +234,7 @@ std::vector<Spec> build_spec(int C, bool dual, int backbone) {
     add(v, p + "mlp.fc2.bias", {D_VIT}, R_VEC);
     add(v, p + "attn.qkv.lnsum", {3 * D_VIT}, R_DERIVED);
     add(v, p + "mlp.fc1.lnsum", {D_MLP}, R_DERIVED);
+    add_vit_fp8(v, p, D_VIT, D_MLP);
   }
   add(v, vp + "norm.weight", {D_VIT}, R_UNUSED);
   add(v, vp + "norm.bias", {D_VIT}, R_UNUSED);
@@ -302,7 +321,7 @@ struct BlobHeader {
   uint64_t packed_single, packed_bytes;
 };
 static_assert(sizeof(BlobHeader) <= BLOB_HEADER, "header fits its slot");
-constexpr uint32_t BLOB_VERSION = 4;
+constexpr uint32_t BLOB_VERSION = 5;   // 5: fp8 entries of the ViT linears (round 6)
 
 struct Buf {  // arena slice: `off` in the whole-batch plan, `off2` in the half-batch plan (two sub-batches on two streams)
   size_t off = 0, bytes = 0, off2 = 0;
@@ -388,8 +407,21 @@ struct dptx_engine {
   // (oracle/fp8_layers.py: the set costs <= 1.5 deg of mean angular error on either synthetic weight family, so that the
   // mode stays within 2 x the bf16 engine's error); with the flag all 19 (round 3's mode: 7.5 - 9 deg, a lossy throughput mode)
   bool fp8_all = false;
+  // DPTX_FLAG_FP8_VIT (round 6): qkv / fc1 / fc2 of every transformer block on e4m3 operands as well -- 45 of the forward's
+  // 127.6 GMAC (proj stays bf16: its operand is the attention kernel's output, which has no e4m3 copy).  oracle/fp8_vit.py: with
+  // per-output-channel weight scales and ONE calibrated scale per activation tensor these layers cost 2.1-2.7 deg of mean
+  // angular error on the default weight family and 1.2-1.9 deg on the trained-like one, about what the six default decoder
+  // convolutions cost -- not the "destroyed output" that rounds 3-5 assumed.
+  bool fp8_vit = false;
+  static bool fp8_vit_weight(const std::string& key) {
+    auto ends = [&](const char* suf) { const size_t n = strlen(suf); return key.size() >= n && key.compare(key.size() - n, n, suf) == 0; };
+    return key.find("pretrained.model.blocks.") != std::string::npos &&
+           (ends("attn.qkv.weight") || ends("mlp.fc1.weight") || ends("mlp.fc2.weight"));
+  }
   bool fp8_use(const std::string& key) const {
-    if (!fp8() || !fp8_weight(key)) return false;
+    if (!fp8()) return false;
+    if (fp8_vit_weight(key)) return fp8_vit && ln_fold && stream16;
+    if (!fp8_weight(key)) return false;
     return fp8_all || key.find("resConfUnit1.") != std::string::npos;
   }
   const void* w8(const std::string& key) const { return d_blob + packed_single + packed_off.at(key) / 2; }
@@ -708,6 +740,38 @@ int pack_host(dptx_engine* e) {
       }
     }
   }
+  if (e->fp8()) {
+    // e4m3 copies of qkv / fc1 / fc2 (DPTX_FLAG_FP8_VIT decides whether they are USED; they are always packed, so that the
+    // blob's layout does not depend on the flag): the weight the bf16 GEMM multiplies -- folded with the LayerNorm's gamma for
+    // qkv / fc1 -- per OUTPUT CHANNEL after a power-of-two scale into (224, 448]; "lnsum8" = column sums of the dequantised copy
+    for (size_t si = 0; si < e->spec.size(); ++si) {
+      const Spec& sp = e->spec[si];
+      if (sp.role != R_LINEAR || !dptx_engine::fp8_vit_weight(sp.key)) continue;
+      const std::vector<float>& W = e->staged.at(sp.key);
+      const size_t N = (size_t)sp.shape[0], K = (size_t)sp.shape[1];
+      const bool fc2 = ends_with(sp.key, "mlp.fc2.weight"), qkv = ends_with(sp.key, "attn.qkv.weight");
+      const std::string stem_key = sp.key.substr(0, sp.key.size() - 6);   // "....attn.qkv." / "....mlp.fc1." / "....mlp.fc2."
+      const std::string blk = sp.key.substr(0, sp.key.find(qkv ? "attn.qkv" : (fc2 ? "mlp.fc2" : "mlp.fc1")));
+      const std::vector<float>* gamma = (!fc2 && e->ln_fold) ? &e->staged.at(blk + (qkv ? "norm1.weight" : "norm2.weight")) : nullptr;
+      uint8_t* d8 = e->host_blob.data() + e->packed_single + e->packed_off.at(sp.key) / 2;
+      float* inv = (float*)(e->host_blob.data() + e->packed_off.at(stem_key + "f8scale"));
+      float* cs8 = fc2 ? nullptr : (float*)(e->host_blob.data() + e->packed_off.at(stem_key + "lnsum8"));
+      for (size_t n = 0; n < N; ++n) {
+        float mx = 0.f;
+        for (size_t k = 0; k < K; ++k) mx = std::max(mx, std::fabs(W[n * K + k] * (gamma ? (*gamma)[k] : 1.0f)));
+        const int sh = mx > 0.f ? (int)std::floor(std::log2(448.0 / (double)mx)) : 0;
+        const float sc = std::ldexp(1.0f, sh);
+        double acc = 0.0;
+        for (size_t k = 0; k < K; ++k) {
+          const uint8_t q = f32_to_e4m3(W[n * K + k] * (gamma ? (*gamma)[k] : 1.0f) * sc);
+          d8[n * K + k] = q;
+          acc += (double)e4m3_to_f32(q);
+        }
+        inv[n] = 1.0f / sc;
+        if (cs8) cs8[n] = (float)(acc / (double)sc);
+      }
+    }
+  }
   e->finalized = true;
   return DPTX_OK;
 }
@@ -954,6 +1018,7 @@ int Run::forward(const void* x, void* y, void* y2) {
   const int ln_nblk = D_VIT / 128;  // records per token row (6 or 8; the row stride is always 8)
   const bool s16 = E->stream16;     // Hn is the (16-bit) token stream; X is not written
   group(DPTX_GROUP_EMBED);
+  int hn_slot = -1;   // fp8 ViT: calibration slot of the token stream's latest e4m3 copy
   {
     // hybrid: the 1x1 projection of the ResNet's 1/16-resolution map (K = 1024); DPT-Large: timm PatchEmbed, a 16x16
     // stride-16 convolution = a dense GEMM over the patch matrix (K = 3*16*16 = 768, misc.hip patchify16)
@@ -968,13 +1033,18 @@ int Run::forward(const void* x, void* y, void* y2) {
     p.R2 = pos; p.r2_bcast = 1; p.r2_fp32 = 1; p.planes = E->pl;
     if (E->ln_fold) { p.C16 = A(E->Hn); p.row_stats = lnst; p.stats_nblk = 8; }
     if (s16) { p.C = A(E->Hn); p.c_fp32 = 0; p.C16 = nullptr; }  // the 16-bit tensor is the stream itself
+    // fp8 ViT (DPTX_FLAG_FP8_VIT): block 0's qkv multiplies the e4m3 copy of the stream
+    hn_slot = E->fp8_use(vp + "blocks.0.attn.qkv.weight") ? q8_produce(A(E->Hn)) : -1;
+    if (hn_slot >= 0) { p.C8 = E->q8(A(E->Hn)); p.q_relu = 0; p.q_scale = E->act_scale[hn_slot]; }
     exec_macs += (double)NP * D_VIT * Kp;
     cat_macs[0] += (double)NP * D_VIT * Kp;
     chk(launch_gemm(dt, p, st), "patch_embed.proj", 0);
   }
   chk(launch_cls_rows(E->mode_of(DPTX_GROUP_VIT), E->f(vp + "cls_token"), pos, s16 ? nullptr : X, B, S, D_VIT,
-                      E->ln_fold ? A(E->Hn) : nullptr, E->ln_fold ? lnst : nullptr, st),
+                      E->ln_fold ? A(E->Hn) : nullptr, E->ln_fold ? lnst : nullptr, st,
+                      hn_slot >= 0 ? E->q8(A(E->Hn)) : nullptr, hn_slot >= 0 ? E->act_scale[hn_slot] : 1.0f),
       "cls_rows");
+  if (hn_slot >= 0) q8_measure(A(E->Hn), (size_t)B * S * D_VIT, 0, hn_slot);
   const int M = B * S;
   const size_t tok_elems = (size_t)M * D_VIT;
   auto tok_tap = [&](int idx, const char* name) {
@@ -1005,8 +1075,10 @@ int Run::forward(const void* x, void* y, void* y2) {
   vit_sums();
 
   // ln: 0 plain; 1 consumer of the folded LayerNorm (qkv, fc1); 2 producer (proj, fc2: 16-bit copy + row statistics)
+  // q8_out (fp8 ViT): the consumer of C multiplies on e4m3 operands -- the epilogue also writes C's e4m3 copy (one calibrated
+  // power-of-two scale per tensor, like the decoder's: Run::conv)
   auto dense = [&](const void* A, int a_fp32, const std::string& wkey, int N, int K, void* C, int c_fp32, const float* bias,
-                   int act, const void* R1, int r1_fp32, int ln = 0, const float* ln_colsum = nullptr) {
+                   int act, const void* R1, int r1_fp32, int ln = 0, const float* ln_colsum = nullptr, bool q8_out = false) {
     GemmParams p;
     gemm_params_dense(p, M, N, K);
     p.A = A; p.a_fp32 = a_fp32; p.W = E->w(wkey); p.C = C; p.c_fp32 = c_fp32; p.bias = bias; p.act = act;
@@ -1016,9 +1088,22 @@ int Run::forward(const void* x, void* y, void* y2) {
     if (ln == 2 && s16) {  // in place on the 16-bit stream: every thread reads exactly the elements it then writes
       p.C = this->A(E->Hn); p.c_fp32 = 0; p.R1 = this->A(E->Hn); p.r1_fp32 = 0; p.C16 = nullptr;
     }
+    int mode = dt;
+    if (E->fp8_use(wkey) && !E->calibrating) {  // e4m3 operands: the e4m3 copies of A and of the (folded) weight
+      p.A = E->q8(A); p.W = E->w8(wkey); p.a_bytes /= 2;
+      p.out_scale = 1.0f / q8_scale_of(A); p.out_scale_v = E->wscale(wkey);
+      if (ln == 1) p.ln_colsum = E->f(wkey.substr(0, wkey.size() - 6) + "lnsum8");
+      mode = MODE_FP8;
+    }
+    int slot = -1;
+    if (q8_out) {
+      slot = q8_produce(p.C);
+      p.C8 = E->q8(p.C); p.q_relu = 0; p.q_scale = E->act_scale[slot];
+    }
     exec_macs += (double)S * N * K;
     cat_macs[0] += (double)S * N * K;
-    chk(launch_gemm(dt, p, st), wkey.c_str(), 0);
+    chk(launch_gemm(mode, p, st), wkey.c_str(), 0);
+    if (slot >= 0) q8_measure(p.C, (size_t)M * N, 0, slot);
   };
 
   // ProjectReadout + reassemble for hook n (hybrid: 3 -> block 8, 4 -> block 11; DPT-Large: 1..4 -> blocks 5, 11, 17, 23,
@@ -1075,6 +1160,11 @@ int Run::forward(const void* x, void* y, void* y2) {
     const std::string p = vp + "blocks." + std::to_string(l) + ".";
     const bool lf = E->ln_fold;
     if (!lf) chk(launch_layernorm(dt, X, E->f(p + "norm1.weight"), E->f(p + "norm1.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln1", 2);
+    // fp8 ViT: the tensors that an e4m3 GEMM reads get their e4m3 copy from the epilogue that produces them -- the stream
+    // after proj (fc1's operand), the GELU output (fc2's), the stream after fc2 (the next block's qkv)
+    const std::string pn = vp + "blocks." + std::to_string(l + 1) + ".";
+    const bool q_fc1 = E->fp8_use(p + "mlp.fc1.weight"), q_fc2 = E->fp8_use(p + "mlp.fc2.weight");
+    const bool q_next = l + 1 < E->depth && E->fp8_use(pn + "attn.qkv.weight");
     dense(A(E->Hn), 0, p + "attn.qkv.weight", 3 * D_VIT, D_VIT, A(E->QKV), 0, E->f(p + "attn.qkv.bias"), 0, nullptr, 0, lf ? 1 : 0,
           lf ? E->f(p + "attn.qkv.lnsum") : nullptr);
     vit_sums();
@@ -1082,13 +1172,13 @@ int Run::forward(const void* x, void* y, void* y2) {
     vit_sums();
     exec_macs += 2.0 * N_HEADS * (double)S * S * 64;
     cat_macs[1] += 2.0 * N_HEADS * (double)S * S * 64;
-    dense(A(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1, lf ? 2 : 0);
+    dense(A(E->AO), 0, p + "attn.proj.weight", D_VIT, D_VIT, X, 1, E->f(p + "attn.proj.bias"), 0, X, 1, lf ? 2 : 0, nullptr, q_fc1);
     vit_sums();
     if (!lf) chk(launch_layernorm(dt, X, E->f(p + "norm2.weight"), E->f(p + "norm2.bias"), A(E->Hn), M, D_VIT, 1e-6f, E->pl, st), "ln2", 2);
     dense(A(E->Hn), 0, p + "mlp.fc1.weight", D_MLP, D_VIT, A(E->F1), 0, E->f(p + "mlp.fc1.bias"), 2, nullptr, 0, lf ? 1 : 0,
-          lf ? E->f(p + "mlp.fc1.lnsum") : nullptr);
+          lf ? E->f(p + "mlp.fc1.lnsum") : nullptr, q_fc2);
     vit_sums();
-    dense(A(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1, lf ? 2 : 0);
+    dense(A(E->F1), 0, p + "mlp.fc2.weight", D_VIT, D_MLP, X, 1, E->f(p + "mlp.fc2.bias"), 0, X, 1, lf ? 2 : 0, nullptr, q_next);
     vit_sums();
     {
       char nm[16];
@@ -1264,7 +1354,8 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if ((cfg->dual_task != 0 && (cfg->dual_task != 1 || cfg->num_channels != 3)) ||
       (cfg->num_channels != 1 && cfg->num_channels != 3) || cfg->max_batch < 1 || cfg->max_batch > 48 ||
       cfg->dtype < DPTX_DTYPE_BF16 || cfg->dtype > DPTX_DTYPE_FP8 || (cfg->ws_form != 0 && cfg->ws_form != 1) ||
-      (cfg->flags & ~(DPTX_FLAG_NO_LN_FOLD | DPTX_FLAG_GROUP_POLICY | DPTX_FLAG_FP32_STREAM | DPTX_FLAG_NO_RANGE_CHECK | DPTX_FLAG_FP8_ALL)) ||
+      (cfg->flags & ~(DPTX_FLAG_NO_LN_FOLD | DPTX_FLAG_GROUP_POLICY | DPTX_FLAG_FP32_STREAM | DPTX_FLAG_NO_RANGE_CHECK | DPTX_FLAG_FP8_ALL |
+                      DPTX_FLAG_FP8_VIT)) ||
       cfg->reserved != 0)
     return DPTX_E_INVALID;
   int x3_groups = 0;
@@ -1286,6 +1377,7 @@ int dptx_create(dptx_handle* out, const dptx_config* cfg) {
   if (e->backbone == DPTX_BACKBONE_VITL16_384) { e->dv = 1024; e->dm = 4096; e->nh = 16; e->depth = 24; }
   e->max_h = max_h;
   e->fp8_all = (cfg->flags & DPTX_FLAG_FP8_ALL) != 0;
+  e->fp8_vit = (cfg->flags & DPTX_FLAG_FP8_VIT) != 0;
   if (cfg->dtype == DPTX_DTYPE_MIXED && cfg->x3_groups == 0 && !(cfg->flags & DPTX_FLAG_GROUP_POLICY)) {
     // default per-layer table of the decoder (oracle/precision_layers.py: per-layer sensitivities on both synthetic weight
     // families; "policy A" of profiles/r03_precision_layers.md): these nine 3x3 convolutions -- 30.6 of the decoder's 57.7

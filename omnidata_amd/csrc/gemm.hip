@@ -39,9 +39,10 @@ hipError_t launch_gemm(int mode, const GemmParams& p0, hipStream_t stream) {
                                (p.gn_cpg & (p.gn_cpg - 1)) != 0 || p.bias != nullptr || p.act != 0))
     return hipErrorInvalidValue;  // statistics are those of the raw accumulators: no bias / activation in front of a GroupNorm
   // LayerNorm fold (kernels.h): producer side needs whole 128-column blocks per tile, consumer side a plain dense epilogue
-  if (p.row_stats != nullptr && (p.N % 128 != 0 || p.stats_nblk != 8 || p.N / 128 > 8 || mode == MODE_FP8)) return hipErrorInvalidValue;
+  // (round 6: both sides of the fold also on the e4m3 kernel -- DPTX_FLAG_FP8_VIT; the fp8 output scale is applied first)
+  if (p.row_stats != nullptr && (p.N % 128 != 0 || p.stats_nblk != 8 || p.N / 128 > 8)) return hipErrorInvalidValue;
   if (p.ln_stats != nullptr && (p.R1 != nullptr || p.R2 != nullptr || p.bias_per_img || p.ln_colsum == nullptr || (p.ln_nblk != 6 && p.ln_nblk != 8) ||
-                                p.c_rpi != 0x7fffffff || p.gn_part != nullptr || mode == MODE_FP8))
+                                p.c_rpi != 0x7fffffff || p.gn_part != nullptr))
     return hipErrorInvalidValue;
   if (mode == MODE_FP8) {  // 128 e4m3 per k-tile row
     if (p.K % 128 != 0 || p.Cin % 128 != 0 || p.M <= 0 || p.N % 32 != 0 || p.ldw < p.K || p.ldw % 16 != 0 || p.gn_part != nullptr)

@@ -154,7 +154,7 @@ hipError_t launch_pos_resize(const float* src, float* dst, int g_old, int gh, in
 // X16 / stats (optional, LayerNorm fold): 16-bit copy of the rows and their (sum, sum of squares) per 128-column block; X may
 // be null (16-bit token stream: no fp32 copy)
 hipError_t launch_cls_rows(int mode, const float* cls, const float* pos, float* X, int B, int S, int C, void* X16, float* stats,
-                           hipStream_t stream);
+                           hipStream_t stream, void* X8 = nullptr, float q_scale = 1.0f);
 
 // out[b][n] = bias[n] + sum_k x[b*x_stride + k] * W[n*ldw + w_off + k]   (x fp32, W 16-bit, out fp32)
 // x16 != 0: x points at 16-bit values (the 16-bit token stream of the single-pass dtypes)

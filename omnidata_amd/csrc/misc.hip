@@ -191,7 +191,7 @@ hipError_t launch_head_out(int mode, const void* X, const float* w, const float*
 // one block per image, 128 threads per 128-column block of the row (C % 128 == 0)
 template <int DT>
 __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X, int S, int C,
-                                uint16_t* __restrict__ X16, float* __restrict__ stats) {
+                                uint16_t* __restrict__ X16, float* __restrict__ stats, uint8_t* __restrict__ X8, float q_scale) {
   __shared__ float red[2][16];
   const int b = blockIdx.x;
   for (int c0 = 0; c0 < C; c0 += blockDim.x) {  // blockDim.x is a multiple of 128
@@ -201,6 +201,8 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
       v = cls[c] + pos[c];
       if (X) X[(long long)b * S * C + c] = v;
       if (X16) X16[(long long)b * S * C + c] = T16<DT>::fromf(v);
+      // fp8 ViT: the e4m3 copy of the token stream (block 0's qkv operand) needs its cls rows too
+      if (X8) X8[(long long)b * S * C + c] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(v * q_scale, 0.f, 0, false) & 0xff);
     }
     if (stats) {  // fixed-order reduction: wave sums, then the two waves of a 128-column block
       const float sm = wave_sum(v), sq = wave_sum(v * v);
@@ -214,13 +216,13 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
   }
 }
 hipError_t launch_cls_rows(int mode, const float* cls, const float* pos, float* X, int B, int S, int C, void* X16, float* stats,
-                           hipStream_t stream) {
+                           hipStream_t stream, void* X8, float q_scale) {
   if (C % 128 != 0) return hipErrorInvalidValue;
   const int nt = C >= 1024 ? 1024 : (C >= 256 ? 256 : 128);
   if (mode == MODE_FP16 || mode == MODE_FP16X3)
-    hipLaunchKernelGGL(cls_rows_kernel<DT_FP16>, dim3(B), dim3(nt), 0, stream, cls, pos, X, S, C, (uint16_t*)X16, stats);
+    hipLaunchKernelGGL(cls_rows_kernel<DT_FP16>, dim3(B), dim3(nt), 0, stream, cls, pos, X, S, C, (uint16_t*)X16, stats, (uint8_t*)X8, q_scale);
   else
-    hipLaunchKernelGGL(cls_rows_kernel<DT_BF16>, dim3(B), dim3(nt), 0, stream, cls, pos, X, S, C, (uint16_t*)X16, stats);
+    hipLaunchKernelGGL(cls_rows_kernel<DT_BF16>, dim3(B), dim3(nt), 0, stream, cls, pos, X, S, C, (uint16_t*)X16, stats, (uint8_t*)X8, q_scale);
   return hipGetLastError();
 }
 

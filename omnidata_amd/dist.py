@@ -27,7 +27,7 @@ def _barrier(device_index: int):
     if dist.get_backend() == "nccl":
         dist.barrier(device_ids=[int(device_index)])
     else:
-        _barrier(device_index)
+        dist.barrier()
 
 
 def broadcast_blob(blob: Optional[torch.Tensor], nbytes: int, device: torch.device, src: int = 0) -> torch.Tensor:

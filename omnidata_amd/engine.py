@@ -201,7 +201,7 @@ class Engine:
         cfg.streams = int(streams)
         cfg.x3_groups = groups_mask(x3_groups)  # dtype "mixed": groups that run 3 MFMAs per product (0 = all but the ViT blocks)
         cfg.backbone = BACKBONE_IDS[backbone]
-        cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold, 2: group-level precision policy only, 4: fp32 token stream in the single-pass dtypes, 8: no fp16 range scan, 16: dtype fp8 with all 19 eligible convs on e4m3)
+        cfg.flags = int(flags)  # include/dptx.h DPTX_FLAG_* (1: no LayerNorm fold, 2: group-level precision policy only, 4: fp32 token stream in the single-pass dtypes, 8: no fp16 range scan, 16: dtype fp8 with all 19 eligible convs on e4m3, 32: dtype fp8 with qkv / fc1 / fc2 of the ViT blocks on e4m3)
         self.cfg = cfg
         self.fp8_calibrated = False
         self.fp8_scales = None  # the scales installed last (calibrate_fp8 / set_fp8_calibration): what a rebuilt engine re-installs

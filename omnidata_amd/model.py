@@ -161,9 +161,11 @@ class DPTDepthModel(_EngineGuards, BaseModel):
     def __init__(self, path: Optional[str] = None, non_negative: bool = True, num_channels: int = 1,
                  backbone: str = "vitb_rn50_384", features: int = 256, readout: str = "project",
                  channels_last: bool = False, use_bn: bool = False, dtype: str = "mixed",
-                 max_batch: int = 32, init_seed: int = 0, x3_groups=0, overflow_fallback: bool = True, fp8_all: bool = False):
+                 max_batch: int = 32, init_seed: int = 0, x3_groups=0, overflow_fallback: bool = True, fp8_all: bool = False,
+                 fp8_vit: bool = False):
         super().__init__()
         self.fp8_all = bool(fp8_all)   # dtype 'fp8': all 19 eligible decoder convs on e4m3 (lossy) instead of the six safe ones
+        self.fp8_vit = bool(fp8_vit)   # dtype 'fp8': qkv / fc1 / fc2 of the ViT blocks on e4m3 too (include/dptx.h DPTX_FLAG_FP8_VIT)
         if backbone not in BACKBONES:
             # blocks.py:42-44: unknown backbones print and assert
             print(f"Backbone '{backbone}' not implemented")
@@ -299,7 +301,8 @@ class DPTDepthModel(_EngineGuards, BaseModel):
                 self._engine.close()
             eng = Engine(num_channels=self.num_channels, max_batch=self._chunk(), dtype=self.engine_dtype,
                          device_id=key[0], non_negative=self.non_negative, max_hw=self.max_hw,
-                         x3_groups=self.x3_groups, backbone=self.backbone, flags=16 if self.fp8_all else 0)
+                         x3_groups=self.x3_groups, backbone=self.backbone,
+                         flags=(16 if self.fp8_all else 0) | (32 if self.fp8_vit else 0))
             eng.load_state_dict(super().state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine
@@ -354,10 +357,11 @@ class DPTDualTaskModel(_EngineGuards, nn.Module):
     """
 
     def __init__(self, dtype: str = "mixed", max_batch: int = 32, init_seed: int = 0, non_negative: bool = True,
-                 x3_groups=0, overflow_fallback: bool = True, fp8_all: bool = False):
+                 x3_groups=0, overflow_fallback: bool = True, fp8_all: bool = False, fp8_vit: bool = False):
         super().__init__()
         self._init_guards(overflow_fallback)
         self.fp8_all = bool(fp8_all)
+        self.fp8_vit = bool(fp8_vit)
         self.engine_dtype = dtype
         self.x3_groups = x3_groups
         self.max_batch = max(1, min(int(max_batch), 48))
@@ -409,7 +413,7 @@ class DPTDualTaskModel(_EngineGuards, nn.Module):
                 self._engine.close()
             eng = Engine(num_channels=3, max_batch=self._chunk(), dtype=self.engine_dtype, device_id=key[0],
                          non_negative=self.non_negative, max_hw=self.max_hw, dual=True, x3_groups=self.x3_groups,
-                         flags=16 if self.fp8_all else 0)
+                         flags=(16 if self.fp8_all else 0) | (32 if self.fp8_vit else 0))
             eng.load_state_dict(super().state_dict())
             self._engine, self._engine_key = eng, key
         return self._engine

@@ -83,7 +83,10 @@ def _blob_offsets(spec_items, dtype_bytes=2):
         derived = []  # entries the engine computes at pack time (engine.hip R_DERIVED)
         if k.endswith("mlp.fc2.bias"):  # LayerNorm fold: column sums of the folded qkv / fc1 weights
             blk = k[:-len("mlp.fc2.bias")]
-            derived = [(blk + "attn.qkv.lnsum", 3 * n), (blk + "mlp.fc1.lnsum", 4 * n)]
+            derived = [(blk + "attn.qkv.lnsum", 3 * n), (blk + "mlp.fc1.lnsum", 4 * n),
+                       # fp8 ViT (round 6): inverse weight scales of the e4m3 copies + column sums of the dequantised folded weights
+                       (blk + "attn.qkv.f8scale", 3 * n), (blk + "mlp.fc1.f8scale", 4 * n), (blk + "mlp.fc2.f8scale", n),
+                       (blk + "attn.qkv.lnsum8", 3 * n), (blk + "mlp.fc1.lnsum8", 4 * n)]
         elif k.endswith(".bias") and ("scratch.refinenet" in k or "scratch.output_conv.0." in k):
             derived = [(k[:-len("bias")] + "f8scale", n)]  # fp8 dtype: per-output-channel inverse weight scales
         for name, m in derived:
@@ -223,3 +226,43 @@ def test_vitl16_host_packing(built_lib):
     e.close()
     with pytest.raises(RuntimeError):
         Engine(num_channels=3, max_batch=1, device_id=None, backbone="vitl16_384", dual=True)   # the dual-task model is the hybrid
+
+
+def test_fp8_vit_host_packing(built_lib):
+    """Round 6, DPTX_FLAG_FP8_VIT: the fp8 blob carries e4m3 copies of qkv / fc1 / fc2 (second plane, byte offset / 2) of the
+    weights the bf16 GEMM multiplies -- qkv / fc1 folded with the LayerNorm's gamma --, quantised per output channel after a
+    power-of-two scale into (224, 448], the inverse scales ('f8scale') and the column sums of the DEQUANTISED copy ('lnsum8':
+    the fold's mean term has to cancel against what the e4m3 MFMA multiplies).  Checked against numpy on the host-only handle."""
+    from omnidata_amd.engine import Engine
+    C = 3
+    sd = random_state_dict(5, C)
+    e = Engine(num_channels=C, max_batch=1, dtype="fp8", device_id=None, flags=32)
+    e.load_state_dict(sd)
+    blob = e.export_packed_host()
+    offs, single = _blob_offsets(state_dict_spec(C).items())
+    assert blob.size == 2 * single == e.packed_bytes
+    f8 = torch.float8_e4m3fn
+    for blk in (0, 7):
+        p = f"pretrained.model.blocks.{blk}."
+        for name, gkey in (("attn.qkv", "norm1.weight"), ("mlp.fc1", "norm2.weight"), ("mlp.fc2", None)):
+            W = sd[p + name + ".weight"].double()
+            Wf = W * sd[p + gkey].double()[None, :] if gkey else W
+            N, K = Wf.shape
+            mx = Wf.abs().amax(1)
+            sc = torch.pow(2.0, torch.floor(torch.log2(448.0 / mx)))
+            want8 = (Wf * sc[:, None]).float().to(f8)
+            off, nbytes = offs[p + name + ".weight"]
+            got8 = torch.from_numpy(blob[single + off // 2: single + off // 2 + N * K].copy()).view(f8).reshape(N, K)
+            # the engine folds in fp32 (W * gamma) before scaling: a product that lands on a rounding boundary may go either way
+            same = (got8.view(torch.uint8) == want8.view(torch.uint8)).float().mean().item()
+            assert same > 0.995, (name, same)
+            assert ((got8.float() - want8.float()).abs() <= torch.exp2(torch.floor(torch.log2(want8.float().abs().clamp_min(2.0 ** -6))) - 3) * 1.001 + 1e-9).all()
+            so, _ = offs[p + name + ".f8scale"]
+            inv = torch.from_numpy(blob[so: so + 4 * N].copy()).view(torch.float32)
+            assert torch.equal(inv, (1.0 / sc).float())
+            assert ((got8.float().abs().amax(1) > 224 * 0.93) & (got8.float().abs().amax(1) <= 448)).all()   # the channel fills the e4m3 range
+            if gkey:
+                lo, _ = offs[p + name + ".lnsum8"]
+                cs = torch.from_numpy(blob[lo: lo + 4 * N].copy()).view(torch.float32)
+                want_cs = (got8.double().sum(1) / sc).float()
+                assert torch.allclose(cs, want_cs, rtol=1e-6, atol=1e-7)

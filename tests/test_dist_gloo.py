@@ -27,7 +27,8 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from omnidata_amd.dist import broadcast_blob, shard_range
+        from omnidata_amd.dist import _barrier, broadcast_blob, shard_range
+        _barrier(0)   # the start-up barrier of build_replicated_engine (device-pinned under nccl, plain under gloo)
         from omnidata_amd.engine import Engine
         from omnidata_amd.weights import random_state_dict
         eng = Engine(num_channels=3, max_batch=2, dtype="bf16", device_id=None)   # host-only handle

@@ -80,6 +80,21 @@ def main():
         fl = 2.0 * M * N * K
         print(f"{name:14s} M={M:8d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s")
         tot_ms += ms; tot_flop += fl
+    if fp8:  # the ViT linears on the e4m3 kernel (DPTX_FLAG_FP8_VIT): a dense GEMM is a 1x1 convolution over a 577 x 1 "image"
+        for name, M, N, K in DENSE:
+            if (only and name not in only) or not name.startswith("vit.") or name == "vit.proj":
+                continue
+            X = torch.randn(B, 577, 1, K, device="cuda").to(torch.float8_e4m3fn)
+            Wt = (torch.randn(N, 1, 1, K, device="cuda") * 16.0).to(torch.float8_e4m3fn)
+            Y = torch.empty(B, 577, 1, N, device="cuda", dtype=tdt)
+            Y8 = torch.empty(B, 577, 1, N, device="cuda", dtype=torch.uint8)
+            bias = torch.randn(N, device="cuda")
+            act = 2 if name == "vit.fc1" else 0
+            ms = timeit(lambda: lib.dptx_op_conv_fp8(X.data_ptr(), Wt.data_ptr(), bias.data_ptr(), None, Y.data_ptr(), Y8.data_ptr(), B, 577, 1,
+                                                     K, N, 1, 1, 0, 0, 577, 1, act, 0, 1.0 / 768, st))
+            fl = 2.0 * B * 577 * N * K
+            print(f"{name + '@fp8':14s} M={B * 577:8d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s")
+            tot_ms += ms; tot_flop += fl
     for name, H, Cin, Cout, k, s, pad, Ho in CONV:
         if only and name not in only:
             continue
