@@ -582,7 +582,7 @@ def main():
                          "accuracy_note": {"fp8": "six decoder convolutions on e4m3: mean angular error within 2 x the bf16 mode's on both "
                                                   "synthetic weight families (tests/test_gpu_fp8.py); NOT validated on the published checkpoints",
                                            "fp8_vit": "six decoder convolutions + qkv / fc1 / fc2 of the 12 ViT blocks on e4m3 (per-channel weight "
-                                                      "scales, one calibrated scale per activation tensor): within 2.5 x the bf16 mode's mean "
+                                                      "scales, one calibrated scale per activation tensor): within 2 x the bf16 mode's mean "
                                                       "angular error on both synthetic weight families (tests/test_gpu_fp8.py, oracle/fp8_vit.py)",
                                            "fp8_all": "all 19 eligible decoder convolutions on e4m3: a lossy throughput mode (7 - 9 deg mean "
                                                       "angular error, tests/test_gpu_fp8.py)",
@@ -598,7 +598,7 @@ def main():
                 gain = a["value"] / dual_bf16 - 1.0
                 a["verdict"] = (f"pays on this box: {100 * gain:+.1f} % over dual bf16 (bar: >= +10 %)" if gain >= 0.10 else
                                 f"does NOT pay on this box: {100 * gain:+.1f} % against dual bf16 (bar: >= +10 %) for "
-                                + ("7-9 deg of" if a["dtype"].startswith("fp8_all") else "up to 2-2.5x the bf16 engine's") + " mean angular error")
+                                + ("7-9 deg of" if a["dtype"].startswith("fp8_all") else "up to 2x the bf16 engine's") + " mean angular error")
 
     if rank == 0:
         total_images = args.batch * world * args.steps

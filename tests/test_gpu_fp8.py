@@ -171,8 +171,9 @@ def test_fp8_vit_error_on_both_weight_families(family):
     (weights per output channel, ONE calibrated scale per activation tensor, LayerNorm fold on the e4m3 kernel with the column
     sums of the dequantised weights).  oracle/fp8_vit.py emulated these layers on the CPU first: 2.1-2.7 deg (default family) /
     1.2-1.9 deg (trained-like) of mean angular error by themselves, which adds in quadrature to the decoder preset's.  Bar:
-    the engine with BOTH stays within 2.5 x the bf16 engine's mean angular error on both families and within 4 deg of it
-    in absolute terms, and the ViT part alone must be what the emulation predicted (<= 3.2 deg / <= 2.3 deg added in quadrature)."""
+    the SAME bar as the default preset's -- the engine with BOTH stays within 2 x the bf16 engine's mean angular error on both
+    families (measured: 4.62 vs 4.18 deg, 1.98 vs 1.07 deg) -- and the ViT part alone must not exceed what the emulation
+    predicted (<= 3.2 deg / <= 2.3 deg added in quadrature; measured 1.23 / 1.09)."""
     from omnidata_amd.weights import random_state_dict
     from oracle.dpt_oracle import dpt_forward
     sd = random_state_dict(0, 3, family=family)
@@ -191,11 +192,13 @@ def test_fp8_vit_error_on_both_weight_families(family):
         res[name] = ((y - ref).pow(2).mean().sqrt().item(), mean_angular_error_deg(y.clamp(0, 1), ref.clamp(0, 1)))
         if name == "fp8+vit":
             scales, amax = m.engine.fp8_calibration()
-            assert len(scales) >= 6 + 1 + 36 and (amax > 0).all()      # decoder copies + the stream after patch-embed + 3 per block
+            # e4m3 tensors: the token stream after patch-embed, after every proj and every fc2 but the last (the next block's qkv
+            # operand), every GELU output, + the decoder preset's six
+            assert len(scales) >= 1 + 12 + 11 + 12 + 6 and (amax > 0).all()
     vit_part = max(res["fp8+vit"][1] ** 2 - res["fp8"][1] ** 2, 0.0) ** 0.5
     print(f"\n[{family}] bf16 {res['bf16'][1]:.2f} deg (rms {res['bf16'][0]:.3e});  fp8 (6 decoder convs) {res['fp8'][1]:.2f} deg;  "
           f"fp8 + ViT qkv/fc1/fc2 {res['fp8+vit'][1]:.2f} deg (rms {res['fp8+vit'][0]:.3e}); ViT part in quadrature {vit_part:.2f} deg")
-    assert res["fp8+vit"][1] <= 2.5 * res["bf16"][1] and res["fp8+vit"][1] <= res["bf16"][1] + 4.0
+    assert res["fp8+vit"][1] <= 2.0 * res["bf16"][1]
     assert vit_part <= (3.2 if family == "default" else 2.3)
 
 
