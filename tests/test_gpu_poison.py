@@ -20,6 +20,7 @@ CASES = [  # dtype, dual, B, streams
     ("fp16x3", False, 2, 2), ("bf16x3", False, 2, 1),
     ("fp8", False, 3, 2), ("fp8", True, 3, 2), ("fp8", True, 3, 1), ("fp8", False, 1, 1),
     ("fp8all", True, 3, 2), ("fp8all", False, 3, 2),   # DPTX_FLAG_FP8_ALL: all 19 eligible decoder convolutions on e4m3
+    ("fp8vit", False, 3, 2), ("fp8vit", True, 3, 1),   # DPTX_FLAG_FP8_VIT (round 6): qkv / fc1 / fc2 on e4m3, e4m3 copies of the token stream
 ]
 
 
@@ -35,8 +36,8 @@ def _fwd(eng, x, dual):
 
 @pytest.mark.parametrize("dtype,dual,B,streams", CASES)
 def test_forward_does_not_depend_on_prior_arena_contents(dtype, dual, B, streams):
-    flags = 16 if dtype == "fp8all" else 0
-    dtype = "fp8" if dtype == "fp8all" else dtype
+    flags = {"fp8all": 16, "fp8vit": 32}.get(dtype, 0)
+    dtype = "fp8" if dtype in ("fp8all", "fp8vit") else dtype
     eng = Engine(num_channels=3, max_batch=B, dtype=dtype, device_id=0, dual=dual, streams=streams, flags=flags)
     eng.load_state_dict(random_dual_state_dict(3) if dual else random_state_dict(3, 3))
     x = synthetic_input(11, B, "normal").to(DEV)

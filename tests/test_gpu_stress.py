@@ -66,11 +66,14 @@ def test_multi_stream_schedule_stress_bit_identical(dtype, streams, iters):
     _stress(dtype, False, 6, streams, iters)
 
 
-@pytest.mark.parametrize("dual,B,iters,flags", [(False, 32, 150, 16), (True, 32, 100, 0), (True, 3, 600, 16), (False, 3, 600, 0)])
+@pytest.mark.parametrize("dual,B,iters,flags", [(False, 32, 150, 16), (True, 32, 100, 0), (True, 3, 600, 16), (False, 3, 600, 0),
+                                                (True, 32, 100, 32), (False, 5, 400, 48)])   # 32 = DPTX_FLAG_FP8_VIT (round 6)
 def test_fp8_stress_bit_identical(dual, B, iters, flags):
     """VERDICT r3 (item 1c): the fp8 decoder under the two-stream schedule, single- and dual-task, at the benchmarked batch
     and at the batch of the round-3 driver failure (B = 3: sub-batches of 2 + 1), against the single-stream result; both
-    presets (flags 16 = DPTX_FLAG_FP8_ALL: all 19 eligible convolutions on e4m3, the configuration that failed in round 3)."""
+    presets (flags 16 = DPTX_FLAG_FP8_ALL: all 19 eligible convolutions on e4m3, the configuration that failed in round 3); round 6:
+    with the ViT linears on e4m3 as well (e4m3 copies of the token stream written by the proj / fc2 / patch-embed epilogues IN PLACE
+    next to the 16-bit stream, the LayerNorm fold on the fp8 kernel)."""
     _stress("fp8", dual, B, 2, iters, flags)
 
 
