@@ -41,6 +41,18 @@ def quant_mx(x, mant_bits, emax, block=32):
     return (yq / s).reshape(shp)
 
 
+def quant_e5m2(x16, div):
+    """What v_cvt_scalef32_pk_bf8_f16 does to an fp16 plane (semantics pinned on the hardware: profiles/r06_bf8_probe.txt): e5m2 = the upper byte of an fp16, so
+    the conversion is fp16(x / div) rounded to nearest even on two mantissa bits, subnormals kept (spacing 2^-16).  No block
+    scale: hi planes are divided by 2 (65504 / 2 stays below e5m2's largest finite value 57344), lo planes -- at most 2^-11 of
+    their hi plane -- are multiplied by 2^10, which also lifts them out of the format's subnormal range; the MFMA's E8M0 scale
+    operand takes the 2^-9 back out.  Returns the de-scaled values as float64."""
+    y = (x16.astype(np.float64) / div).astype(np.float16)
+    u = y.view(np.uint16).astype(np.uint32)
+    r = ((u + 0x7F + ((u >> 8) & 1)) & 0xFF00).astype(np.uint16)
+    return r.view(np.float16).astype(np.float64) * div
+
+
 def study(M=512, N=256, K=2304, seed=0):
     rng = np.random.default_rng(seed)
     a = np.maximum(rng.standard_normal((M, K)), 0.0) * (1.0 + 3.0 * (rng.random((M, K)) < 0.01))   # post-ReLU, 1 % outliers
@@ -64,6 +76,12 @@ def study(M=512, N=256, K=2304, seed=0):
         rows.append((f"1 MFMA + cross terms on {name} (block 32)", cost, a_hi @ w_hi.T + cross))
         cross_w = q(a_hi) @ q(w_lo).T
         rows.append((f"1 MFMA + ONLY a_hi w_lo on {name} (the XT = 2 analogue)", 1.0 + (cost - 1.0) / 2, a_hi @ w_hi.T + cross_w))
+    # round 6, the form that was BUILT AND MEASURED (profiles/r06_x3_bf8_cross_attempt.patch; not shipped: the in-register
+    # conversions cost more than the MFMA passes they save, profiles/r06_experiments.md section 7): e5m2 operands straight from
+    # the fp16 planes, fixed scales, no block maxima
+    h16 = lambda t: t.astype(np.float16)   # noqa: E731
+    cross = quant_e5m2(h16(a_hi), 2.0) @ quant_e5m2(h16(w_lo), 2.0 ** -10).T + quant_e5m2(h16(a_lo), 2.0 ** -10) @ quant_e5m2(h16(w_hi), 2.0).T
+    rows.append(("1 MFMA + cross terms on e5m2, fixed scales (round 6's kernel attempt)", 2.0, a_hi @ w_hi.T + cross))
     print(f"product [{M} x {K}] . [{N} x {K}]^T, post-ReLU activations with 1 % outliers, N(0, 1/K) weights; errors relative to rms(output)")
     print(f"{'form':72s} {'MFMA-equivalents':>16s} {'rms error':>12s} {'max error':>12s}")
     for name, cost, y in rows:
