@@ -88,7 +88,7 @@ def measure_traffic(args, lib_hash):
         print("measure_traffic: rocprofv3 not found", file=sys.stderr)
         return None
     tmp = tempfile.mkdtemp(prefix="dptx_traffic_", dir="/tmp")
-    env = dict(os.environ, DPTX_STREAMS="1", DPTX_STAGE_GROUPS="1", TMPDIR="/tmp")
+    env = dict(os.environ, DPTX_STREAMS="1", TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--steps", "3", "--batch", str(args.batch), "--dtype", args.dtype,
@@ -129,7 +129,7 @@ def measure_traffic(args, lib_hash):
     fam_bytes = corr * f_fam * 1024.0 / fw + w_fam * 1024.0 / fw2
     all_bytes = corr * f_all * 1024.0 / fw + w_all * 1024.0 / fw2
     launches = nl / fw
-    return {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, DPTX_STREAMS=1 DPTX_STAGE_GROUPS=1, bench.py "
+    return {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, DPTX_STREAMS=1, bench.py "
                       f"--traffic-child B={args.batch} {args.dtype} {args.task}",
             "library": lib_hash, "forwards": fw, "gemm_family_fetch_kb_raw_per_forward": f_fam / fw,
             "gemm_family_write_kb_per_forward": w_fam / fw2, "gfx950_fetch_correction": corr,
