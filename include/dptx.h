@@ -391,6 +391,16 @@ int dptx_op_upsample2x(int32_t dtype, const void* X, void* Y, int32_t B, int32_t
  * ln_stats[m][0 .. ln_nblk) (float2, row stride 8 records; ln_nblk = K / 128 = 6 or 8) and ln_colsum[n] = sum_k W[n][k]. */
 int dptx_op_gemm_ln(int32_t dtype, const void* A, const void* W, const float* bias, void* C, int32_t M, int32_t N, int32_t K,
                     int32_t act, const float* ln_stats, const float* ln_colsum, int32_t ln_nblk, float ln_eps, void* stream);
+/* Dense GEMM with the PRODUCER epilogue of the LayerNorm fold on the 16-bit token stream (what the proj / fc2 launches run,
+ * vit.py:150-151 x = x + attn(...) / x + mlp(...)): C[M,N] (16-bit) <- C + A[M,K] W[N,K]^T + bias in place, and the (sum, sum of
+ * squares) of every new row per 128-column block as float2 records row_stats[m][0 .. N / 128) (row stride 8 records; N a
+ * multiple of 128, <= 1024). */
+int dptx_op_gemm_stream(int32_t dtype, const void* A, const void* W, const float* bias, void* C, float* row_stats, int32_t M,
+                        int32_t N, int32_t K, void* stream);
+/* The same on the fp32 token stream (the parity mode's ViT blocks): X[M,N] (fp32) <- X + A W^T + bias in place, the 16-bit image
+ * of the new rows into C16 (what the next qkv / fc1 GEMM multiplies), records as above. */
+int dptx_op_gemm_stream32(int32_t dtype, const void* A, const void* W, const float* bias, float* X, void* C16, float* row_stats,
+                          int32_t M, int32_t N, int32_t K, void* stream);
 /* Fused tail of the head (dpt_depth.py:93-98): Interpolate(x2, bilinear, align_corners=True) -> Conv2d(128,32,3,pad 1)
  * -> ReLU -> Conv2d(32,C,1) -> ReLU(if relu_out).  H0 NHWC 16-bit [B,Hs,Ws,128]; W2 16-bit [32][3][3][128]
  * (O,kh,kw,I); b2 fp32[32]; w4 fp32 [C][32]; b4 fp32[C]; y NCHW fp32 [B,C,2Hs,2Ws].  BF16 / FP16 only; C <= 3. */

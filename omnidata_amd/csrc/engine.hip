@@ -2010,6 +2010,27 @@ int dptx_op_gemm_ln(int32_t dtype, const void* A, const void* W, const float* bi
   return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
 }
 
+// dense GEMM with the LayerNorm fold's PRODUCER epilogue on the 16-bit token stream (what the proj / fc2 launches run):
+// C <- C + A W^T + bias in place, and (sum, sum of squares) of every new row per 128-column block into row_stats[m][0 .. N / 128)
+int dptx_op_gemm_stream(int32_t dtype, const void* A, const void* W, const float* bias, void* C, float* row_stats, int32_t M,
+                        int32_t N, int32_t K, void* stream) {
+  GemmParams p;
+  gemm_params_dense(p, M, N, K);
+  p.A = A; p.W = W; p.C = C; p.R1 = C; p.bias = bias; p.planes = g_op_planes;
+  p.row_stats = row_stats; p.stats_nblk = 8;
+  return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
+// the same on the fp32 token stream of the parity mode: X (fp32) <- X + A W^T + bias in place, its 16-bit image into C16
+int dptx_op_gemm_stream32(int32_t dtype, const void* A, const void* W, const float* bias, float* X, void* C16, float* row_stats,
+                          int32_t M, int32_t N, int32_t K, void* stream) {
+  GemmParams p;
+  gemm_params_dense(p, M, N, K);
+  p.A = A; p.W = W; p.C = X; p.c_fp32 = 1; p.R1 = X; p.r1_fp32 = 1; p.C16 = C16; p.bias = bias; p.planes = g_op_planes;
+  p.row_stats = row_stats; p.stats_nblk = 8;
+  return launch_gemm(dtype, p, (hipStream_t)stream) == hipSuccess ? DPTX_OK : DPTX_E_HIP;
+}
+
 int dptx_op_head_tail(int32_t dtype, const void* H0, const void* W2, const float* b2, const float* w4, const float* b4, float* y,
                       int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t relu_out, void* stream) {
   return launch_head_tail(dtype, H0, W2, b2, w4, b4, y, DPTX_IO_FP32, B, Hs, Ws, C, relu_out, (hipStream_t)stream, g_op_planes) == hipSuccess

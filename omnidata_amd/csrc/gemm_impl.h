@@ -799,14 +799,59 @@ __device__ __forceinline__ void pp_mma_tile(PpFrags& f0, PpFrags& f1, const char
 // them eight CONSECUTIVE columns -- a 16-byte store, 32 bytes contiguous per row and instruction.  No accumulator goes
 // through LDS (the staged epilogue moves 512 KB per tile through it and takes 12-18 k cycles of a 57-72 k-cycle K = 768
 // tile); LDS only holds the tile's 256 bias / column-sum values and the (mu, rstd) row table.
-// Launches it serves (launch_cfg): no residual, no row remap, no per-image bias, no statistics, 16-bit C, one plane.
-template <int DT>
+// Launches it serves (launch_cfg): no row remap, no per-image bias, no GroupNorm statistics, 16-bit C, one plane.
+// R1 (round 6: proj / fc2 on the 16-bit token stream, the second convolution of a RCU): ONE 16-bit residual with C's rows and
+// columns -- it may BE C (the in-place stream: a lane reads exactly the 16 bytes it later writes).  All 16 loads of a lane's
+// tile share are issued before anything else (64 registers: the k-loop's fragment registers are free here), so their latency
+// runs under the bias fill, the wait for the next tile's DMA and the barrier -- once per tile.  With R1 the launch may also
+// be the PRODUCER side of the LayerNorm fold (p.row_stats: (sum, sum of squares) of every row per 128-column block): a lane
+// sums its eight columns in order, then the staged epilogue's butterfly over the 16 eight-column chunks of a block is
+// replayed level by level -- chunk c = 8 (wn & 1) + 4 j + 2 pr + lh, so level 1 is the lane ^ 32 partner, levels 2 and 3 are
+// in-lane (pr, j) and level 4 pairs the waves wn, wn ^ 1 through LDS: the same additions in the same association, the
+// records are bit-identical to the staged form's (tests/test_gpu_ops.py::test_gemm_launch_forms_agree_bit_for_bit).
+// RES: 0 no residual; 1 R1 16-bit (all loads up front); 2 R1 + R2 16-bit (RCU conv2 + the fusion path: both one 32-row block
+// ahead -- all of them up front would be 128 registers next to the 128 accumulators).  (The fp32 token stream of the parity
+// mode -- R1 and C fp32, plus a 16-bit copy -- was built in this form too and is SLOWER than the staged epilogue: 10 bytes
+// per element in 32-byte pieces per row and instruction; profiles/r06_experiments.md section 8.  It stays staged.)
+template <int DT, int RES>
 __device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem, int m0, int n0, int wm, int wn, int lr, int lh,
                                                 int tid, f32x16_t (&acc)[4][2], bool dma_in_flight, const char* lds_ln) {
+  constexpr bool R1 = RES != 0;
   float* sbias = (float*)smem;          // [256]
   float* scol = sbias + 256;            // [256] column sums of the folded weight
   float2* lnrow = (float2*)(scol + 256);  // [256] (mu, rstd)
+  float2* spart = lnrow + 256;          // [256 rows][4 wave columns] row-statistics partials (R1 && row_stats)
   const bool lnf = p.ln_stats != nullptr;
+  u32x4_t rres[4][2][2];      // RES 1: R1 of the lane's whole tile share
+  u32x4_t rnext[2][2][2][2];  // RES 2: block i in set i & 1, [set][j][pr][R1 / R2]
+  auto row_off = [&](int i) -> long long {
+    const int m = m0 + wm * 128 + i * 32 + lr;
+    return ((long long)p.c_row_off + (m < p.M ? m : m0)) * p.ldc + n0 + wn * 64 + 8 * lh;
+  };
+  auto load_next = [&](int i) {   // i: compile-time after unrolling
+    const long long ro = row_off(i);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const long long o = ro + j * 32 + 16 * pr;
+        if constexpr (RES == 2) {
+          rnext[i & 1][j][pr][0] = *(const u32x4_t*)((const uint16_t*)p.R1 + o);
+          rnext[i & 1][j][pr][1] = *(const u32x4_t*)((const uint16_t*)p.R2 + o);
+        }
+      }
+  };
+  if constexpr (RES == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint16_t* rrow = (const uint16_t*)p.R1 + row_off(i);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) rres[i][j][pr] = *(const u32x4_t*)(rrow + j * 32 + 16 * pr);
+    }
+  }
+  if constexpr (RES == 2) load_next(0);
   if (tid < 256) {
     sbias[tid] = p.bias != nullptr ? p.bias[n0 + tid] : 0.f;
     scol[tid] = lnf ? p.ln_colsum[n0 + tid] : 0.f;
@@ -827,11 +872,16 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem,
   if (dma_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const bool stats = R1 && p.row_stats != nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wm * 128 + i * 32 + lr;
     const int m = m0 + row;
     const bool ok = m < p.M;
+    float csm[2][2], csq[2][2];
+    if constexpr (RES == 2) {
+      if (i + 1 < 4) load_next(i + 1);
+    }
     float2 ms = make_float2(0.f, 1.f);
     if (lnf) ms = lnrow[row];
     uint16_t* crow = (uint16_t*)p.C + ((long long)p.c_row_off + (ok ? m : m0)) * p.ldc + n0;
@@ -867,7 +917,62 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem,
 #pragma unroll
           for (int e = 0; e < 8; e += 2) gelu_erf2(v[e], v[e + 1]);
         }
+        if constexpr (R1) {
+          {
+            float f[8];
+            if constexpr (RES == 2) unpack8x<DT, 1>(rnext[i & 1][j][pr][0], rnext[i & 1][j][pr][0], f);
+            else unpack8x<DT, 1>(rres[i][j][pr], rres[i][j][pr], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += f[e];
+          }
+          if constexpr (RES == 2) {
+            float f[8];
+            unpack8x<DT, 1>(rnext[i & 1][j][pr][1], rnext[i & 1][j][pr][1], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += f[e];
+          }
+          if (stats) {   // chunk sums in column order, as the staged epilogue's threads form them
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sm += v[e]; sq = fmaf(v[e], v[e], sq); }
+            csm[j][pr] = sm;
+            csq[j][pr] = sq;
+          }
+        }
         if (ok) store8f<DT, 1>(crow + col, 0, v);
+      }
+    }
+    if constexpr (R1) {
+      if (stats) {
+        float sm[2], sq[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float a[2], b[2];
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {   // level 1: chunk c ^ 1 is the lane ^ 32 partner's
+            a[pr] = csm[j][pr] + __shfl_xor(csm[j][pr], 32, 64);
+            b[pr] = csq[j][pr] + __shfl_xor(csq[j][pr], 32, 64);
+          }
+          sm[j] = a[0] + a[1];               // level 2: pr
+          sq[j] = b[0] + b[1];
+        }
+        if (lh == 0) spart[row * 4 + wn] = make_float2(sm[0] + sm[1], sq[0] + sq[1]);   // level 3: j
+      }
+    }
+  }
+  if constexpr (R1) {
+    if (stats) {
+      __syncthreads();
+      // level 4: the two waves of a 128-column block; wave (wm, wn even) writes the records of its rows' block wn / 2
+      if ((wn & 1) == 0 && lh == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wm * 128 + i * 32 + lr;
+          const int m = m0 + row;
+          const float2 x = spart[row * 4 + wn], y = spart[row * 4 + wn + 1];
+          if (m < p.M)
+            ((float2*)p.row_stats)[((long long)p.c_row_off + m) * p.stats_nblk + ((n0 + wn * 64) >> 7)] = make_float2(x.x + y.x, x.y + y.y);
+        }
       }
     }
   }
@@ -893,7 +998,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, char* smem,
 // -- all <= 0: profiles/r02_experiments.md; the three that were kernels of their own are in the git history, round 5's tree.)
 // DIRECT: transposed accumulators + epilogue_direct (the launches with a plain epilogue: qkv, fc1, the first convolution of a
 // RCU, layerN_rn, output_conv.0); everything else about the kernel is the same.
-template <int DT, bool RELU_A, int PLE = 1, bool DIRECT = false>
+template <int DT, bool RELU_A, int PLE = 1, int DIRECT = 0>   // DIRECT: 0 staged epilogue, 1 + RES: epilogue_direct<DT, RES>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2, PL = 1;
@@ -1083,7 +1188,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     asm volatile("s_barrier" ::: "memory");                                                                        \
     DPTX_STAMP(2);                                                                                                 \
     pp_read(f0, sa, sb, wn, lr, lh, 0);            /* slot 2 */                                                    \
-    pp_mma_tile<DT, RELU_A, ZC, DIRECT>(f0, f1, sa, sb, wn, lr, lh, acc);                                          \
+    pp_mma_tile<DT, RELU_A, ZC, DIRECT != 0>(f0, f1, sa, sb, wn, lr, lh, acc);                                          \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* what group 1 reads in its next slot has landed */         \
     DPTX_STAMP(3);                                                                                                 \
     asm volatile("s_barrier" ::: "memory");                                                                        \
@@ -1094,7 +1199,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
     const char* sa = ahi_ptr(kt & 1);              /* slot 1 */                                                    \
     const char* sb = w_ptr(kt & 1);                                                                                \
     pp_read(f0, sa, sb, wn, lr, lh, 0);                                                                            \
-    pp_mma_tile<DT, RELU_A, ZC, DIRECT>(f0, f1, sa, sb, wn, lr, lh, acc);                                          \
+    pp_mma_tile<DT, RELU_A, ZC, DIRECT != 0>(f0, f1, sa, sb, wn, lr, lh, acc);                                          \
     /* its DMA of the previous slot 2 (A rows 0..127 of THIS tile) has landed before group 0 reads it in slot 2 */ \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
     DPTX_STAMP(1);                                                                                                 \
@@ -1143,7 +1248,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmParams p) {
 #endif
       if constexpr (DIRECT) {
         (void)trow; (void)wp_ok;
-        epilogue_direct<DT>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, more,
+        epilogue_direct<DT, DIRECT - 1>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, more,
                             p.ln_stats != nullptr ? smem + LN_LDS : nullptr);
       } else if (wp_ok && p.row_stats == nullptr)
         epilogue<DT, BM, BN, TM, TN, PLE, NT, SLABS, false, true>(p, smem + 4 * HALF, em0, en0, ewm, ewn, elr, elh, etid, acc, 0, more, trow,
@@ -1555,16 +1660,26 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
       // plain epilogue (bias, LayerNorm fold, activation, one 16-bit plane): the transposed-accumulator form that stores
       // straight from the registers.  DPTX_DIRECT=0: the staged epilogue everywhere (A/B runs; results agree bit for bit)
       static int direct_on = -1;
-      if (direct_on < 0) { const char* e = getenv("DPTX_DIRECT"); direct_on = e ? atoi(e) : 1; }
-      const bool direct = direct_on && !(p.debug_flags & 1) && PLE == 1 && p.R1 == nullptr && p.R2 == nullptr && !p.bias_per_img && p.c_rpi == 0x7fffffff &&
-                          !p.c_fp32 && p.C8 == nullptr && p.C16 == nullptr && p.row_stats == nullptr && p.gn_part == nullptr &&
-                          p.out_scale == 0.f;
+      if (direct_on < 0) { const char* e = getenv("DPTX_DIRECT"); direct_on = e ? atoi(e) : 2; }
+      const bool direct_any = direct_on && !(p.debug_flags & 1) && PLE == 1 && !p.bias_per_img && p.c_rpi == 0x7fffffff &&
+                              p.C8 == nullptr && p.gn_part == nullptr && p.out_scale == 0.f;
+      const bool direct = direct_any && p.R1 == nullptr && p.R2 == nullptr && p.row_stats == nullptr && !p.c_fp32 && p.C16 == nullptr;
+      // round 6: residuals and the producer side of the LayerNorm fold in the direct form (epilogue_direct RES 1, 2): proj / fc2
+      // on the 16-bit token stream, the second convolution of a RCU with and without the fusion path.
+      // DPTX_DIRECT=1: round 5's set only
+      const bool direct_res = direct_any && direct_on >= 2 && p.R1 != nullptr && !p.a_relu && p.ln_stats == nullptr;
+      const int res = !direct_res ? 0
+                      : (!p.r1_fp32 && !p.c_fp32 && p.C16 == nullptr && p.R2 == nullptr) ? 1
+                      : (!p.r1_fp32 && !p.c_fp32 && p.C16 == nullptr && p.R2 != nullptr && !p.r2_fp32 && !p.r2_bcast && p.row_stats == nullptr) ? 2
+                      : 0;
       if constexpr (PLE == 1) {
         if (direct) {
-          if (p.a_relu) go(gemm_pp_kernel<DT, true, 1, true>);
-          else go(gemm_pp_kernel<DT, false, 1, true>);
+          if (p.a_relu) go(gemm_pp_kernel<DT, true, 1, 1>);
+          else go(gemm_pp_kernel<DT, false, 1, 1>);
           return hipGetLastError();
         }
+        if (res == 1) { go(gemm_pp_kernel<DT, false, 1, 2>); return hipGetLastError(); }
+        if (res == 2) { go(gemm_pp_kernel<DT, false, 1, 3>); return hipGetLastError(); }
       }
       if (p.a_relu) go(gemm_pp_kernel<DT, true, PLE>);
       else go(gemm_pp_kernel<DT, false, PLE>);

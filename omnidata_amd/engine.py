@@ -94,6 +94,8 @@ ABI = [
     ("dptx_op_conv_groupnorm", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 12 + [C.c_float, _vp, _vp]),
     ("dptx_op_upsample2x", C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     ("dptx_op_gemm_ln", C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, C.c_float, _vp]),
+    ("dptx_op_gemm_stream", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    ("dptx_op_gemm_stream32", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     ("dptx_op_head_tail", C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
 ]
 

@@ -52,6 +52,78 @@ def test_gemm_epilogues(dtype, M, K):
     assert rel_err(op_gemm(dtype, A32, W, bias, c_fp32=True), ref) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,K", [(18464, 768), (18464, 3072), (9232, 768), (1731, 768)])  # proj / fc2 at B = 32, a half batch, a small batch
+def test_gemm_token_stream_producer_forms_bitwise(dtype, M, K):
+    """proj / fc2 on the 16-bit token stream: C <- C + A W^T + bias IN PLACE plus the LayerNorm fold's row statistics
+    (dptx_op_gemm_stream).  Round 6: at B = 32 the launch takes the register-direct epilogue of the 256x256 kernel (residual
+    loads up front, the statistics' butterfly replayed across lanes / registers / the two waves of a 128-column block); the
+    staged epilogue (debug flag 1) and the one-block-per-tile launch (flag 3) must give the same bits in C AND in the records,
+    and both must be right: C against fp32 of the same expression, the records against sums of the fp32 rows."""
+    lib = load_library()
+    N = 768
+    A, W = rnd(M, K, dtype=dtype, seed=11), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=12)
+    bias = torch.randn(N, device=DEV)
+    C0 = rnd(M, N, dtype=dtype, seed=13)
+    outs = []
+    try:
+        for flags in (0, 1, 3):
+            lib.dptx_debug_set_gemm_flags(flags)
+            C = C0.clone()
+            stats = torch.full((M, 8, 2), float("nan"), device=DEV)
+            rc = lib.dptx_op_gemm_stream(DTYPES[dtype], ptr(A), ptr(W), ptr(bias), ptr(C), ptr(stats), M, N, K, stream())
+            assert rc == 0
+            outs.append((C, stats))
+    finally:
+        lib.dptx_debug_set_gemm_flags(0)
+    for C, stats in outs[1:]:
+        assert torch.equal(C, outs[0][0])
+        assert torch.equal(stats[:, :N // 128], outs[0][1][:, :N // 128])
+    C, stats = outs[0]
+    ref = A.float() @ W.float().t() + bias + C0.float()
+    assert rel_err(C.float(), ref) < OUT_TOL[dtype]
+    blk = ref.double().view(M, N // 128, 128)
+    assert rel_err(stats[:, :N // 128, 0], blk.sum(2)) < 1e-4        # statistics of the fp32 values, not of the rounded stream
+    assert rel_err(stats[:, :N // 128, 1], (blk * blk).sum(2)) < 1e-4
+    assert torch.isnan(stats[:, N // 128:]).all()                    # records of blocks the launch does not own stay untouched
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,K", [(18464, 768), (18464, 3072), (1731, 768)])
+def test_gemm_fp32_token_stream_producer_forms_bitwise(dtype, M, K):
+    """The parity mode's proj / fc2: fp32 stream in place + its 16-bit image + row statistics (dptx_op_gemm_stream32).  These
+    launches stay on the staged epilogue (a register-direct form was built in round 6 and measured slower:
+    profiles/r06_experiments.md section 8); the launch forms that exist -- persistent tile loop, one block per tile -- must agree
+    bit for bit, and be right."""
+    lib = load_library()
+    N = 768
+    A, W = rnd(M, K, dtype=dtype, seed=21), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=22)
+    bias = torch.randn(N, device=DEV)
+    X0 = torch.randn(M, N, device=DEV)
+    outs = []
+    try:
+        for flags in (0, 1, 3):
+            lib.dptx_debug_set_gemm_flags(flags)
+            X = X0.clone()
+            C16 = torch.zeros(M, N, dtype=TDT[dtype], device=DEV)
+            stats = torch.full((M, 8, 2), float("nan"), device=DEV)
+            rc = lib.dptx_op_gemm_stream32(DTYPES[dtype], ptr(A), ptr(W), ptr(bias), ptr(X), ptr(C16), ptr(stats), M, N, K, stream())
+            assert rc == 0
+            outs.append((X, C16, stats))
+    finally:
+        lib.dptx_debug_set_gemm_flags(0)
+    for X, C16, stats in outs[1:]:
+        assert torch.equal(X, outs[0][0]) and torch.equal(C16, outs[0][1])
+        assert torch.equal(stats[:, :N // 128], outs[0][2][:, :N // 128])
+    X, C16, stats = outs[0]
+    ref = A.float() @ W.float().t() + bias + X0
+    assert rel_err(X, ref) < 2e-5
+    assert torch.equal(C16, X.to(TDT[dtype]))                        # the 16-bit image is the rounding of the stored fp32 value
+    blk = ref.double().view(M, N // 128, 128)
+    assert rel_err(stats[:, :N // 128, 0], blk.sum(2)) < 1e-4
+    assert rel_err(stats[:, :N // 128, 1], (blk * blk).sum(2)) < 1e-4
+
+
 def conv_ref(X, Wt, bias, stride, pad_t, pad_l, Ho, Wo, a_relu):
     x = X.float().permute(0, 3, 1, 2)
     if a_relu:
