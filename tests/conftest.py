@@ -37,3 +37,13 @@ def built_lib():
     """libdptx.so, built in-tree if missing (hipcc cross-compiles without a GPU)."""
     from omnidata_amd.build import build
     return build()
+
+
+@pytest.fixture(autouse=True)
+def _seed_torch_rngs(request):
+    """Every test starts from the same torch RNG state, host and device.  Several GPU tests draw small operands (biases, head
+    weights) with torch.randn(device=...) and no generator: their error-vs-fp64 margins then depended on what ran before them
+    (round 6: test_fp16x3_fused_head_tail[1-192-192-1-1] read 2.10e-5 against a 2e-5 bound once in six full runs)."""
+    import torch
+    torch.manual_seed(20260930)   # seeds the CUDA generators too (lazily: nothing happens on a box without a GPU)
+    yield
